@@ -1,0 +1,122 @@
+"""Generate the golden vectors under tests/golden/ by running the UNMODIFIED reference.
+
+Build-container only (needs /root/reference; see oracle/ref_harness.py for the import stubs).
+Usage:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden [case ...]     (default: all small)
+        PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden cfg1            (≈10+ min of CPU)
+
+Each fixture is pure data: the model hyper-parameters and seeds that regenerate the synthetic
+weights/inputs (valle_amd.weights), the inputs themselves, the reference's output codes, a few
+logits rows captured by forward hooks on the reference's own predict layers, and — for sampled
+runs — the Exp(1) noise the reference's torch.multinomial consumed (re-drawn from the same
+seed; that oracle(noise) == reference(multinomial) is asserted here before anything is written).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+import valle_amd  # noqa: E402,F401
+from valle_amd.config import ModelConfig  # noqa: E402
+from valle_amd.weights import synthetic_inputs, synthetic_state_dict  # noqa: E402
+from oracle import valle_oracle as vo  # noqa: E402
+from oracle.ref_harness import build_reference_model  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# name -> (model kwargs, S, P, top_k, temperature, sample_seed, enroll_len, ar probe steps)
+CASES = {
+    # BASELINE.json configs[0]: d=256 nhead=4 L=4, greedy, 3 s prompt, S=10 -> 161 tokens
+    "cfg0_greedy": (dict(decoder_dim=256, nhead=4, num_decoder_layers=4, prefix_mode=1), 10, 225, 1, 1.0, None, None, (0, 1, 80, 160)),
+    "cfg0_topk10": (dict(decoder_dim=256, nhead=4, num_decoder_layers=4, prefix_mode=1), 10, 225, 10, 1.0, 1234, None, (0, 1, 80, 160)),
+    "cfg0_temp_nofilter": (dict(decoder_dim=256, nhead=4, num_decoder_layers=4, prefix_mode=1), 6, 40, -100, 0.7, 77, None, (0, 50)),
+    # options the reference's own smoke test walks through (valle_test.py:106-135)
+    "tiny_mode0": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=0), 8, 16, 5, 1.0, 5, None, (0, 7)),
+    "tiny_mode1_bos": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=1, prepend_bos=True), 8, 16, 5, 1.0, 6, None, (0, 7)),
+    "tiny_mode2_q6": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=2, num_quantizers=6), 8, 16, 5, 1.0, 7, 4, (0, 7)),
+    "tiny_mode4": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=4), 9, 16, 3, 1.3, 8, 3, (0, 7)),
+    "tiny_q1": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=0, num_quantizers=1), 5, 12, 1, 1.0, None, None, (0, 3)),
+    "tiny_q2_unshared": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=1, num_quantizers=2, share_embedding=False), 5, 12, 1, 1.0, None, None, (0, 3)),
+    # BASELINE.json configs[1]: d=1024 nhead=16 L=12, top-k 10, S=47 -> 753 tokens x 8 codebooks
+    "cfg1_topk10": (dict(decoder_dim=1024, nhead=16, num_decoder_layers=12, prefix_mode=1), 47, 225, 10, 1.0, 1234, None, (0, 1, 376, 752)),
+}
+SMALL = [k for k in CASES if not k.startswith("cfg1")]
+V = 1025
+
+
+def run_case(name: str):
+    kw, S, P, top_k, temp, sseed, enroll, probes = CASES[name]
+    cfg = ModelConfig(**kw)
+    sd = synthetic_state_dict(cfg, seed=0)
+    x, x_lens, y = synthetic_inputs(S, P, 8, seed=1)
+    enroll_x_lens = None if enroll is None else torch.tensor([enroll], dtype=torch.int32)
+    ref = build_reference_model(cfg, sd)
+
+    ar_log, nar_log = [], {}
+    ref.ar_predict_layer.register_forward_hook(lambda m, i, o: ar_log.append(o.detach()[0].clone()))
+    if cfg.num_quantizers > 1:
+        # tied predict layers are distinct modules sharing a Parameter (valle.py:268-271)
+        for si, layer in enumerate(ref.nar_predict_layers):
+            layer.register_forward_hook(lambda m, i, o, si=si: nar_log.__setitem__(si, o.detach()[0, :8].clone()))
+
+    if sseed is not None:
+        torch.manual_seed(sseed)
+    t0 = time.time()
+    with torch.no_grad():
+        codes = ref.inference(x, x_lens, y, enroll_x_lens=enroll_x_lens, top_k=top_k, temperature=temp)
+    dt = time.time() - t0
+    n_pass = len(ar_log)
+    print(f"[{name}] reference: codes {tuple(codes.shape)} passes {n_pass} in {dt:.1f}s", flush=True)
+
+    noise = None
+    if top_k != 1:
+        # the reference drew one (1,V) exponential per pass from the global CPU generator
+        torch.manual_seed(sseed)
+        noise = torch.stack([torch.empty(1, V).exponential_(1)[0] for _ in range(n_pass)])
+
+    # pin the oracle before writing anything
+    m = vo.OracleModel(sd, cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, cfg.prefix_mode,
+                       cfg.prepend_bos, cfg.num_quantizers)
+    tr = {}
+    oc = vo.inference_cached(m, x, x_lens, y, enroll_x_lens, top_k, temp, noise, trace=tr)
+    assert torch.equal(oc, codes), f"{name}: cached oracle differs from the reference"
+    err = max(float((tr["ar_logits"][i] - ar_log[i]).abs().max()) for i in range(len(tr["ar_logits"])))
+    print(f"[{name}] cached oracle == reference codes; max |logit diff| {err:.2e}", flush=True)
+    assert err < 1e-3
+    if cfg.decoder_dim <= 256:
+        of = vo.inference_faithful(m, x, x_lens, y, enroll_x_lens, top_k, temp, noise)
+        assert torch.equal(of, codes), f"{name}: faithful oracle differs from the reference"
+
+    probes = [p for p in probes if p < n_pass]
+    out = dict(
+        cfg=np.array([cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, cfg.prefix_mode,
+                      int(cfg.prepend_bos), cfg.num_quantizers, int(cfg.share_embedding)], dtype=np.int32),
+        weight_seed=np.int32(0), input_seed=np.int32(1),
+        x=x.numpy().astype(np.int16), x_lens=x_lens.numpy(), y=y.numpy().astype(np.int16),
+        enroll=np.int32(-1 if enroll is None else enroll),
+        top_k=np.int32(top_k), temperature=np.float32(temp),
+        codes=codes.numpy().astype(np.int16), n_pass=np.int32(n_pass),
+        ar_probe_steps=np.array(probes, dtype=np.int32),
+        ar_probe_logits=torch.stack([ar_log[p] for p in probes]).numpy(),
+    )
+    if nar_log:
+        out["nar_probe_logits"] = torch.stack([nar_log[i] for i in sorted(nar_log)]).numpy()
+    if noise is not None:
+        out["exp_noise"] = noise.numpy()
+        out["sample_seed"] = np.int32(sseed)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"[{name}] wrote {os.path.getsize(os.path.join(OUT, name + '.npz')) / 1024:.0f} KiB", flush=True)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
+    for c in (sys.argv[1:] or SMALL):
+        run_case(c)

@@ -1,0 +1,368 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+A plain PyTorch-CPU fp32 restatement of the reference's ``VALLE.inference`` hot path
+(/root/reference/valle/models/valle.py:961-1137) written functionally over a ``state_dict``.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; nothing under ``vall-e_amd/`` does.
+
+Parity status: **pinned** — ``oracle/gen_golden.py`` imports the unmodified reference model
+code in the build container, loads the same name-seeded synthetic weights into it and writes
+the vectors under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks this file against
+them (tokens exact, logits <= 1e-5).  The reference's own tests hold no numerical vectors for
+this path (valle/tests/valle_test.py:91-135 are shape smoke tests).
+
+Two variants:
+  * ``inference_faithful`` — no KV cache, whole sequence recomputed at every AR step, same
+    op order as valle.py:1012-1057 / 1115-1134.  This is what is timed as "the reference's
+    CPU path" (bench.py cpu_baseline, kind "port").
+  * ``ArCache`` / ``inference_cached`` — prefill + single-token steps over a KV cache; the
+    executable spec of the HIP kernels.  Identical results.
+
+The arithmetic bottoms out in the same torch ops the reference reaches: F.linear,
+F.layer_norm, F.scaled_dot_product_attention, F.softmax, torch.topk, torch.multinomial.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+NUM_AUDIO_TOKENS = 1024  # valle/models/macros.py:5
+LN_EPS = 1e-5
+
+
+# ----------------------------------------------------------------------------- building blocks
+def sine_pe(length: int, dim: int) -> torch.Tensor:
+    """valle/modules/embedding.py:75-88 (fp32 table, sin on even / cos on odd channels)."""
+    position = torch.arange(0, length, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * -(math.log(10000.0) / dim))
+    pe = torch.zeros(length, dim)
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def add_position(x: torch.Tensor, alpha: torch.Tensor, start: int = 0) -> torch.Tensor:
+    """SinePositionalEmbedding.forward, embedding.py:93-97: x*1.0 + alpha*pe[start:start+T]."""
+    T, d = x.shape[-2], x.shape[-1]
+    pe = sine_pe(max(4000, start + T), d)[start : start + T]
+    return x * 1.0 + alpha * pe
+
+
+def layer_norm(x, w, b):
+    """valle/modules/transformer.py:57-74 -> F.layer_norm(eps=1e-5)."""
+    return F.layer_norm(x, (x.shape[-1],), w, b, LN_EPS)
+
+
+def ada_layer_norm(x, stage_emb, pw, pb, w, b):
+    """AdaptiveLayerNorm.forward, transformer.py:93-108."""
+    d = x.shape[-1]
+    weight, bias = torch.split(F.linear(stage_emb, pw, pb), d, dim=-1)
+    return weight * layer_norm(x, w, b) + bias
+
+
+def self_attention(x, in_w, in_b, out_w, out_b, nhead: int, mask: Optional[torch.Tensor]):
+    """MultiheadAttention.forward -> F.multi_head_attention_forward (activation.py:407-427;
+    torch/nn/functional.py:6206-6640): packed in-proj, heads = contiguous channel blocks,
+    SDPA with additive -inf mask, out-proj.  x: (N, d) single sequence."""
+    N, d = x.shape
+    hd = d // nhead
+    qkv = F.linear(x, in_w, in_b)
+    q, k, v = qkv.chunk(3, dim=-1)
+    q = q.reshape(N, nhead, hd).transpose(0, 1).unsqueeze(0)  # (1,H,N,hd)
+    k = k.reshape(N, nhead, hd).transpose(0, 1).unsqueeze(0)
+    v = v.reshape(N, nhead, hd).transpose(0, 1).unsqueeze(0)
+    am = None
+    if mask is not None:  # bool, True = masked (functional.py:6154-6180)
+        am = torch.zeros(mask.shape, dtype=x.dtype).masked_fill_(mask, float("-inf"))
+    o = F.scaled_dot_product_attention(q, k, v, am, 0.0, False)
+    o = o.squeeze(0).transpose(0, 1).reshape(N, d)
+    return F.linear(o, out_w, out_b), (k.squeeze(0), v.squeeze(0))
+
+
+class _Layer:
+    """Weights of one TransformerEncoderLayer (transformer.py:181-258)."""
+
+    def __init__(self, sd, prefix, adaptive):
+        g = lambda n: sd[f"{prefix}.{n}"]
+        self.in_w, self.in_b = g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias")
+        self.out_w, self.out_b = g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias")
+        self.w1, self.b1 = g("linear1.weight"), g("linear1.bias")
+        self.w2, self.b2 = g("linear2.weight"), g("linear2.bias")
+        self.adaptive = adaptive
+        if adaptive:
+            self.n = [
+                (g(f"{n}.project_layer.weight"), g(f"{n}.project_layer.bias"), g(f"{n}.norm.weight"), g(f"{n}.norm.bias"))
+                for n in ("norm1", "norm2")
+            ]
+        else:
+            self.n = [(g(f"{n}.weight"), g(f"{n}.bias")) for n in ("norm1", "norm2")]
+
+    def norm(self, i, x, stage_emb):
+        if self.adaptive:
+            pw, pb, w, b = self.n[i]
+            return ada_layer_norm(x, stage_emb, pw, pb, w, b)
+        w, b = self.n[i]
+        return layer_norm(x, w, b)
+
+
+def encoder_layer(L: _Layer, x, nhead, mask, stage_emb=None):
+    """Pre-norm branch of TransformerEncoderLayer.forward, transformer.py:296-302, 315-334."""
+    a, kv = self_attention(L.norm(0, x, stage_emb), L.in_w, L.in_b, L.out_w, L.out_b, nhead, mask)
+    x = x + a
+    x = x + F.linear(F.relu(F.linear(L.norm(1, x, stage_emb), L.w1, L.b1)), L.w2, L.b2)
+    return x, kv
+
+
+def ar_mask(S: int, A: int) -> torch.Tensor:
+    """valle.py:1010, 1018-1033: text rows see text only; audio rows see all text + causal audio."""
+    m = torch.zeros(S + A, S + A, dtype=torch.bool)
+    m[:S, S:] = True
+    m[S:, S:] = torch.triu(torch.ones(A, A, dtype=torch.bool), diagonal=1)
+    return m
+
+
+# ----------------------------------------------------------------------------- sampling
+def top_k_filter_(logits: torch.Tensor, top_k: int) -> torch.Tensor:
+    """top_k_top_p_filtering with top_p=1.0, valle.py:1254-1260 — IN PLACE, ties at the k-th
+    value are all kept (strict '<')."""
+    if top_k > 0:
+        top_k = min(max(top_k, 1), logits.size(-1))
+        thr = torch.topk(logits, top_k)[0][..., -1, None]
+        logits[logits < thr] = -float("inf")
+    return logits
+
+
+def topk_sampling(logits: torch.Tensor, top_k: int, temperature: float, exp_noise: Optional[torch.Tensor] = None):
+    """valle.py:1287-1302.  With ``exp_noise`` (a (1,V) tensor of Exp(1) draws) the multinomial
+    is evaluated as argmax(p / q), which is what torch.multinomial(p, 1) does on CPU with q
+    drawn from the generator (aten/src/ATen/native/Sampling / SURVEY.md §9 v2)."""
+    if temperature != 1.0:
+        logits = logits / temperature
+    logits = top_k_filter_(logits, top_k)
+    p = F.softmax(logits, dim=-1)
+    if exp_noise is None:
+        return torch.multinomial(p, num_samples=1)
+    return torch.argmax(p / exp_noise, dim=-1, keepdim=True)
+
+
+# ----------------------------------------------------------------------------- the model view
+class OracleModel:
+    def __init__(self, sd: Dict[str, torch.Tensor], d_model: int, nhead: int, num_layers: int,
+                 prefix_mode: int = 0, prepend_bos: bool = False, num_quantizers: int = 8,
+                 nar_scale_factor: float = 1.0):
+        self.sd = sd
+        self.d, self.nhead, self.L = d_model, nhead, num_layers
+        self.dn = int(d_model * nar_scale_factor)
+        self.nar_nhead = int(nhead * nar_scale_factor)
+        self.nar_L = int(num_layers * nar_scale_factor)
+        self.prefix_mode, self.prepend_bos, self.Q = prefix_mode, prepend_bos, num_quantizers
+        self.ar_layers = [_Layer(sd, f"ar_decoder.layers.{i}", False) for i in range(self.L)]
+        if self.Q > 1:
+            self.nar_layers = [_Layer(sd, f"nar_decoder.layers.{i}", True) for i in range(self.nar_L)]
+
+    # -- AR pieces ---------------------------------------------------------------------------
+    def ar_text(self, text: torch.Tensor) -> torch.Tensor:  # (S,) -> (S,d); valle.py:995-997
+        e = F.embedding(text, self.sd["ar_text_embedding.word_embeddings.weight"])
+        return add_position(e, self.sd["ar_text_position.alpha"])
+
+    def ar_audio(self, y: torch.Tensor, start: int = 0) -> torch.Tensor:  # valle.py:1013-1015
+        e = F.embedding(y, self.sd["ar_audio_embedding.word_embeddings.weight"])
+        return add_position(e, self.sd["ar_audio_position.alpha"], start)
+
+    def ar_stack(self, xy: torch.Tensor, mask) -> torch.Tensor:  # valle.py:1035-1038
+        x = xy
+        for L in self.ar_layers:
+            x, _ = encoder_layer(L, x, self.nhead, mask)
+        return layer_norm(x, self.sd["ar_decoder.norm.weight"], self.sd["ar_decoder.norm.bias"])
+
+    def ar_logits(self, h_last: torch.Tensor) -> torch.Tensor:  # valle.py:1039
+        return F.linear(h_last, self.sd["ar_predict_layer.weight"])
+
+    # -- NAR pieces --------------------------------------------------------------------------
+    def nar_stack(self, xy: torch.Tensor, stage: int) -> torch.Tensor:  # valle.py:1125-1127
+        e = self.sd[f"nar_stage_embeddings.{stage}.word_embeddings.weight"]
+        x = xy
+        for L in self.nar_layers:
+            x, _ = encoder_layer(L, x, self.nar_nhead, None, e)
+        g = lambda n: self.sd[f"nar_decoder.norm.{n}"]
+        return ada_layer_norm(x, e, g("project_layer.weight"), g("project_layer.bias"), g("norm.weight"), g("norm.bias"))
+
+    def nar(self, text: torch.Tensor, text_len: int, prompts: torch.Tensor, y: torch.Tensor,
+            enroll_x_lens, trace: Optional[dict] = None) -> List[torch.Tensor]:
+        """valle.py:1059-1134.  text (S,), prompts (P,Q), y (P+T,) = prompt cb0 + AR tokens.
+        Returns the Q-1 NAR code rows, each (T,)."""
+        sd, P = self.sd, prompts.shape[0]
+        y_emb = F.embedding(y, sd["nar_audio_embeddings.0.word_embeddings.weight"]).clone()
+        if self.prefix_mode in (2, 4):  # valle.py:1068-1079
+            enrolled_len = int(enroll_x_lens.max().item())
+            text = torch.cat([text[:1], text[enrolled_len - 1:]])
+            text_len = text_len - (enrolled_len - 2)
+        x = add_position(F.embedding(text, sd["nar_text_embedding.word_embeddings.weight"]),
+                         sd["nar_text_position.alpha"])
+        codes = []
+        if self.prefix_mode != 0:  # valle.py:1110-1113
+            for j in range(1, self.Q):
+                y_emb[:P] += F.embedding(prompts[:, j], sd[f"nar_audio_embeddings.{j}.word_embeddings.weight"])
+        for i in range(self.Q - 1):
+            y_pos = add_position(y_emb, sd["nar_audio_position.alpha"])
+            xy = torch.cat([x, y_pos], dim=0)
+            h = self.nar_stack(xy, i)
+            logits = F.linear(h[text_len + P:], sd[f"nar_predict_layers.{i}.weight"])
+            if trace is not None:
+                trace.setdefault("nar_logits", []).append(logits.clone())
+            samples = torch.argmax(logits, dim=-1)
+            codes.append(samples)
+            if i < self.Q - 2:
+                emb = sd[f"nar_audio_embeddings.{i + 1}.word_embeddings.weight"]
+                if self.prefix_mode == 0:  # valle.py:1104-1108
+                    y_emb[:P] += F.embedding(prompts[:, i + 1], emb)
+                y_emb[P:] += F.embedding(samples, emb)
+        return codes
+
+
+def _stop(logits, samples, n_generated: int, S: int) -> bool:
+    """valle.py:1044-1048."""
+    return bool(
+        torch.argmax(logits, dim=-1)[0] == NUM_AUDIO_TOKENS
+        or samples[0, 0] == NUM_AUDIO_TOKENS
+        or n_generated > S * 16
+    )
+
+
+@torch.no_grad()
+def inference_faithful(m: OracleModel, x, x_lens, y, enroll_x_lens=None, top_k: int = -100,
+                       temperature: float = 1.0, exp_noise: Optional[torch.Tensor] = None,
+                       max_new_tokens: Optional[int] = None, trace: Optional[dict] = None,
+                       skip_nar: bool = False) -> torch.Tensor:
+    """No-cache restatement of VALLE.inference (valle.py:986-1137).  ``exp_noise`` (steps,V):
+    row i feeds the multinomial of forward pass i; None -> torch.multinomial on the global RNG,
+    exactly like the reference.  ``max_new_tokens`` truncates the AR loop (bench sampling only).
+    """
+    assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3 and y.shape[0] == 1
+    assert torch.all(x_lens > 0)
+    text = x[0]
+    S = int(x_lens.max())
+    X = m.ar_text(text)
+    prompts = y[0]
+    P = prompts.shape[0]
+    yy = prompts[:, 0]
+    if m.prepend_bos:
+        yy = F.pad(yy, (1, 0), value=NUM_AUDIO_TOKENS + 1)
+    bos = int(m.prepend_bos)
+    step = 0
+    while True:
+        xy = torch.cat([X, m.ar_audio(yy)], dim=0)
+        h = m.ar_stack(xy, ar_mask(S, yy.shape[0]))
+        logits = m.ar_logits(h[-1:])
+        if trace is not None:
+            trace.setdefault("ar_logits", []).append(logits[0].clone())
+        noise = None if exp_noise is None else exp_noise[step : step + 1]
+        samples = topk_sampling(logits, top_k, temperature, noise)
+        n_gen = yy.shape[0] - P - bos
+        if _stop(logits, samples, yy.shape[0] - P, S) or (max_new_tokens is not None and n_gen >= max_new_tokens):
+            if yy.shape[0] == P and max_new_tokens is None:  # valle.py:1049-1052
+                raise SyntaxError("well trained model shouldn't reach here.")
+            break
+        yy = torch.cat([yy, samples[0]])
+        step += 1
+    codes = [yy[P + bos:]]
+    if m.Q == 1 or skip_nar:
+        return torch.stack(codes, dim=-1).unsqueeze(0)
+    codes += m.nar(text, S, prompts, yy[bos:], enroll_x_lens, trace)
+    return torch.stack(codes, dim=-1).unsqueeze(0)
+
+
+# ----------------------------------------------------------------------------- cached variant
+class ArCache:
+    """KV-cached AR decode: prefill over [text | prompt] with the reference mask, then one row
+    per step.  Hidden states of earlier rows never change, so this computes the
+    same function as the no-cache loop."""
+
+    def __init__(self, m: OracleModel):
+        self.m = m
+        self.k: List[torch.Tensor] = []
+        self.v: List[torch.Tensor] = []
+
+    def prefill(self, text: torch.Tensor, yy: torch.Tensor) -> torch.Tensor:
+        m = self.m
+        S = text.shape[0]
+        self.S, self.n_audio = S, yy.shape[0]
+        x = torch.cat([m.ar_text(text), m.ar_audio(yy)], dim=0)
+        mask = ar_mask(S, yy.shape[0])
+        self.k, self.v = [], []
+        for L in m.ar_layers:
+            x, (k, v) = encoder_layer(L, x, m.nhead, mask)
+            self.k.append(k)
+            self.v.append(v)
+        h = layer_norm(x[-1:], m.sd["ar_decoder.norm.weight"], m.sd["ar_decoder.norm.bias"])
+        return m.ar_logits(h)
+
+    def step(self, token: torch.Tensor) -> torch.Tensor:
+        """token: (1,) int64 — the audio token appended at audio position ``n_audio``."""
+        m = self.m
+        x = m.ar_audio(token, start=self.n_audio)  # (1,d)
+        self.n_audio += 1
+        d, H = m.d, m.nhead
+        hd = d // H
+        for li, L in enumerate(m.ar_layers):
+            hN = L.norm(0, x, None)
+            qkv = F.linear(hN, L.in_w, L.in_b)
+            q, k, v = qkv.chunk(3, dim=-1)
+            q = q.reshape(1, H, hd).transpose(0, 1)
+            self.k[li] = torch.cat([self.k[li], k.reshape(1, H, hd).transpose(0, 1)], dim=1)
+            self.v[li] = torch.cat([self.v[li], v.reshape(1, H, hd).transpose(0, 1)], dim=1)
+            s = torch.matmul(q, self.k[li].transpose(1, 2)) / math.sqrt(hd)
+            a = torch.matmul(F.softmax(s, dim=-1), self.v[li])  # (H,1,hd)
+            a = a.transpose(0, 1).reshape(1, d)
+            x = x + F.linear(a, L.out_w, L.out_b)
+            x = x + F.linear(F.relu(F.linear(L.norm(1, x, None), L.w1, L.b1)), L.w2, L.b2)
+        h = layer_norm(x, m.sd["ar_decoder.norm.weight"], m.sd["ar_decoder.norm.bias"])
+        return m.ar_logits(h)
+
+
+@torch.no_grad()
+def inference_cached(m: OracleModel, x, x_lens, y, enroll_x_lens=None, top_k: int = -100,
+                     temperature: float = 1.0, exp_noise: Optional[torch.Tensor] = None,
+                     trace: Optional[dict] = None, forced: Optional[torch.Tensor] = None,
+                     skip_nar: bool = False) -> torch.Tensor:
+    """Same contract as ``inference_faithful`` with a KV cache.  ``forced`` (T,) teacher-forces
+    the AR tokens (the sample is still drawn and recorded in ``trace['ar_samples']``)."""
+    text = x[0]
+    S = int(x_lens.max())
+    prompts = y[0]
+    P = prompts.shape[0]
+    yy = prompts[:, 0]
+    if m.prepend_bos:
+        yy = F.pad(yy, (1, 0), value=NUM_AUDIO_TOKENS + 1)
+    bos = int(m.prepend_bos)
+    cache = ArCache(m)
+    logits = cache.prefill(text, yy)
+    step = 0
+    while True:
+        if trace is not None:
+            trace.setdefault("ar_logits", []).append(logits[0].clone())
+        noise = None if exp_noise is None else exp_noise[step : step + 1]
+        samples = topk_sampling(logits, top_k, temperature, noise)
+        if trace is not None:
+            trace.setdefault("ar_samples", []).append(int(samples[0, 0]))
+        if forced is not None:
+            if step >= forced.shape[0]:
+                break
+            samples = forced[step].reshape(1, 1)
+        elif _stop(logits, samples, yy.shape[0] - P, S):
+            if yy.shape[0] == P:  # valle.py:1049-1052
+                raise SyntaxError("well trained model shouldn't reach here.")
+            break
+        yy = torch.cat([yy, samples[0]])
+        step += 1
+        if forced is None and (yy.shape[0] - P) > S * 16:
+            break  # the next pass could only stop (valle.py:1047); skip computing it
+        logits = cache.step(samples[0])
+    codes = [yy[P + bos:]]
+    if m.Q == 1 or skip_nar:
+        return torch.stack(codes, dim=-1).unsqueeze(0)
+    codes += m.nar(text, S, prompts, yy[bos:], enroll_x_lens, trace)
+    return torch.stack(codes, dim=-1).unsqueeze(0)

@@ -1,0 +1,73 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+
+
+class Golden:
+    """A committed fixture: reference outputs + everything needed to rebuild its inputs."""
+
+    def __init__(self, name):
+        from valle_amd.config import ModelConfig
+
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.name = name
+        c = [int(v) for v in z["cfg"]]
+        self.cfg = ModelConfig(decoder_dim=c[0], nhead=c[1], num_decoder_layers=c[2], prefix_mode=c[3],
+                               prepend_bos=bool(c[4]), num_quantizers=c[5], share_embedding=bool(c[6]))
+        self.weight_seed = int(z["weight_seed"])
+        self.x = torch.from_numpy(z["x"].astype(np.int64))
+        self.x_lens = torch.from_numpy(z["x_lens"])
+        self.y = torch.from_numpy(z["y"].astype(np.int64))
+        e = int(z["enroll"])
+        self.enroll_x_lens = None if e < 0 else torch.tensor([e], dtype=torch.int32)
+        self.top_k = int(z["top_k"])
+        self.temperature = float(z["temperature"])
+        self.codes = torch.from_numpy(z["codes"].astype(np.int64))
+        self.n_pass = int(z["n_pass"])
+        self.ar_probe_steps = [int(v) for v in z["ar_probe_steps"]]
+        self.ar_probe_logits = torch.from_numpy(z["ar_probe_logits"])
+        self.nar_probe_logits = torch.from_numpy(z["nar_probe_logits"]) if "nar_probe_logits" in z else None
+        self.exp_noise = torch.from_numpy(z["exp_noise"]) if "exp_noise" in z else None
+        self.sample_seed = int(z["sample_seed"]) if "sample_seed" in z else None
+
+    def state_dict(self):
+        from valle_amd.weights import synthetic_state_dict
+
+        return synthetic_state_dict(self.cfg, self.weight_seed)
+
+    def oracle(self, sd=None):
+        from oracle import valle_oracle as vo
+
+        c = self.cfg
+        return vo.OracleModel(sd if sd is not None else self.state_dict(), c.decoder_dim, c.nhead,
+                              c.num_decoder_layers, c.prefix_mode, c.prepend_bos, c.num_quantizers)
+
+
+@pytest.fixture(scope="session")
+def golden_cache():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+
+    return get
