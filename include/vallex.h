@@ -1,0 +1,160 @@
+/*
+ * vallex.h — C ABI of the MI355X-native VALL-E inference engine (libvallex.so).
+ *
+ * The reference (RuntimeRacer/vall-e) is pure Python and has no FFI: its "operator interface"
+ * for this path is the method valle.models.VALLE.inference (valle/models/valle.py:961-1137)
+ * called from valle/bin/infer.py:197-204 and :241-248.  This header is the boundary a
+ * maintainer binds instead (ctypes stub in INTEGRATION.md); every entry point cites the piece
+ * of the reference it replaces.  Plain C types only: no torch / HIP types in any signature
+ * (a stream is passed as void* = hipStream_t, NULL = the default stream).
+ *
+ * Conventions
+ *   - every function returns VX_OK (0) or an error code; vx_last_error() gives the message of
+ *     the last failure on the calling thread.
+ *   - id / code arrays are int64 (torch.LongTensor layout, as the reference passes them) and
+ *     may live in device OR host memory — the engine detects which.  The caller owns them.
+ *   - one engine per device per thread; calls on one engine must not overlap.
+ *   - work is ordered after everything already enqueued on `stream`, and `stream` is made to
+ *     wait for the engine's work before the call returns (the engine runs on its own stream
+ *     so that the AR step can be replayed as a hipGraph).
+ */
+#ifndef VALLEX_H
+#define VALLEX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vx_engine vx_engine;
+
+enum vx_status {
+  VX_OK = 0,
+  VX_ERR_ARG = 1,         /* bad argument (the reference would trip an assert, valle.py:986-991) */
+  VX_ERR_HIP = 2,         /* a HIP runtime call failed */
+  VX_ERR_STATE = 3,       /* call order violated (e.g. decode before prefill) */
+  VX_ERR_CAPACITY = 4,    /* S / P / T exceed the capacities given at vx_create */
+  VX_ERR_UNSUPPORTED = 5, /* configuration outside the built scope */
+  VX_ERR_WEIGHTS = 6      /* unknown key, wrong shape or missing tensor */
+};
+
+enum vx_precision {
+  VX_PREC_F32 = 0, /* fp32 weights, KV cache and activations: the token-exact parity mode */
+  VX_PREC_BF16 = 1 /* bf16 matrices / KV cache / GEMM operands, fp32 residual stream + accumulate */
+};
+
+enum vx_stop_reason {
+  VX_STOP_NONE = 0,
+  VX_STOP_EOS_ARGMAX = 1, /* argmax(logits) == 1024      (valle.py:1045) */
+  VX_STOP_EOS_SAMPLE = 2, /* sampled token == 1024       (valle.py:1046) */
+  VX_STOP_LENGTH = 3,     /* generated > 16 * text_len   (valle.py:1047) */
+  VX_STOP_MAX_NEW = 4     /* engine-level max_new_tokens (not in the reference) */
+};
+
+enum vx_flags {
+  VX_FLAG_TRACE_LOGITS = 1, /* keep the (1025,) AR logits of every pass (parity tests) */
+  VX_FLAG_NO_GRAPH = 2,     /* launch the AR step kernel by kernel instead of as a hipGraph */
+  VX_FLAG_SIMPLE_ROWS = 4   /* bf16 mode: use the scalar-FMA row kernels instead of MFMA (A/B checks) */
+};
+
+/* Mirrors VALLE.__init__ (valle.py:727-760) / get_model (models/__init__.py:112-124). */
+typedef struct vx_config {
+  int32_t struct_size;     /* = sizeof(vx_config) */
+  int32_t d_model;         /* --decoder-dim */
+  int32_t nhead;           /* --nhead */
+  int32_t num_layers;      /* --num-decoder-layers */
+  int32_t nar_d_model;     /* int(d_model * scale_factor), valle.py:83 */
+  int32_t nar_nhead;       /* int(nhead * scale_factor),   valle.py:234 */
+  int32_t nar_num_layers;  /* int(L * scale_factor),       valle.py:241 */
+  int32_t num_quantizers;  /* --num-quantizers (1..8) */
+  int32_t prefix_mode;     /* --prefix-mode 0/1/2/4 */
+  int32_t prepend_bos;     /* --prepend-bos */
+  int32_t precision;       /* enum vx_precision */
+  int32_t max_text;        /* capacity: phoneme ids per utterance */
+  int32_t max_audio;       /* capacity: audio rows = [BOS] + prompt frames + generated frames */
+  int32_t device;          /* HIP device ordinal */
+  int32_t flags;           /* enum vx_flags */
+} vx_config;
+
+/* Sampling / stop-rule parameters of one AR decode (VALLE.inference args top_k, temperature,
+ * valle.py:967-968; topk_sampling valle.py:1287-1302). */
+typedef struct vx_decode_params {
+  int32_t struct_size;
+  int32_t top_k;            /* <= 0: no filtering (the reference default -100) */
+  float temperature;        /* logits / temperature when != 1.0 */
+  int32_t max_new_tokens;   /* < 0: reference stop rule only */
+  const float* exp_noise;   /* optional (noise_rows, 1025) Exp(1) draws, row i feeds pass i:      */
+  int64_t noise_rows;       /*   sample = argmax(p / q) == torch.multinomial(p, 1) on that stream  */
+  uint64_t seed;            /* device counter RNG seed, used when exp_noise == NULL */
+  const int64_t* forced;    /* optional teacher forcing: token appended at pass i = forced[i]     */
+  int32_t n_forced;         /*   (the sample is still drawn and recorded); decode ends after them */
+} vx_decode_params;
+
+const char* vx_last_error(void);
+
+/* VALLE(...) constructor + .to(device) (valle.py:727-760; bin/infer.py:137,147). */
+int vx_create(const vx_config* cfg, vx_engine** out);
+void vx_destroy(vx_engine* e);
+
+/* model.load_state_dict(checkpoint["model"], strict=True) (bin/infer.py:139-143), one tensor
+ * at a time.  `key` is the reference state_dict key, `data` fp32 (host or device), row-major. */
+int vx_set_weight(vx_engine* e, const char* key, const float* data, const int64_t* shape, int32_t ndim);
+/* Optional: the fp32 sine table of SinePositionalEmbedding (modules/embedding.py:75-88),
+ * (rows, dim).  which: 0 = AR width, 1 = NAR width.  If never set, the engine fills it with
+ * host sinf/cosf (same formula; may differ from torch's table in the last ulp). */
+int vx_set_sine_table(vx_engine* e, int32_t which, const float* data, int64_t rows, int64_t dim);
+/* strict=True check (every key present) + model.eval(); precomputes the per-stage AdaptiveLayerNorm
+ * scale/shift vectors (modules/transformer.py:93-108, constant per stage at inference). */
+int vx_finalize_weights(vx_engine* e);
+
+/* valle.py:994-1010 + the first pass of the AR loop (valle.py:1012-1039): embeds text and
+ * codebook-0 prompt (+BOS), runs the AR stack under the reference mask, fills the KV cache and
+ * leaves the logits of pass 0.  text: (S,), prompt_cb0: (P,). */
+int vx_ar_prefill(vx_engine* e, const int64_t* text, int32_t S, const int64_t* prompt_cb0, int32_t P, void* stream);
+
+/* The AR while-loop (valle.py:1012-1057): sample, stop test, append, next pass.  Asynchronous
+ * w.r.t. the host except for periodic polls of the stop flag. */
+int vx_ar_decode(vx_engine* e, const vx_decode_params* p, void* stream);
+
+/* Blocks until the decode has finished.  tokens: host buffer of `capacity` int64 (generated
+ * codebook-0 tokens, valle.py:1059).  n_pass = number of logits rows produced. */
+int vx_ar_result(vx_engine* e, int64_t* tokens, int32_t capacity, int32_t* n_tokens, int32_t* stop_reason,
+                 int32_t* n_pass);
+
+/* The NAR stages (valle.py:1063-1134).  text_nar: (S2,) phoneme ids after the prefix_mode 2/4
+ * trim (done by the host shim, valle.py:1068-1079); prompts: (P, Q) row-major; ar_tokens: (T,);
+ * codes_out: (T, Q) int64 row-major, column 0 = ar_tokens (valle.py:1136-1137). */
+int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
+           const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream);
+
+/* Device-time of the last calls, measured with HIP events on the engine's stream:
+ * out[0] prefill ms, out[1] AR decode ms, out[2] NAR ms, out[3] AR passes, out[4] graph launches. */
+int vx_get_timings(vx_engine* e, double* out, int32_t n);
+
+/* Parity-test taps: copies an internal buffer to host memory (synchronises the engine stream).
+ * names: "ar_logits" (n_pass x 1025 fp32 with VX_FLAG_TRACE_LOGITS, else the last row),
+ * "ar_sampled" / "ar_argmax" (int32 per pass), "nar_logits" (T x 1024 fp32 of the last stage),
+ * "ar_x" (d fp32 residual stream of the last AR row), "nar_x" (N x d fp32 after the last stage). */
+int vx_read_buffer(vx_engine* e, const char* name, void* dst, int64_t offset_bytes, int64_t nbytes);
+
+/* Kernel-level entry points (device pointers, fp32 unless noted) used by tests/ to check each
+ * HIP kernel against the oracle's corresponding torch op.  prec selects the storage type the
+ * kernel is instantiated for (weights / KV: fp32 or bf16).  All run on `stream` and return
+ * after enqueueing. */
+int vx_op_layernorm(int32_t prec, const float* x, const float* gamma, const float* beta, const float* ada_w,
+                    const float* ada_b, void* out /* fp32 or bf16 per prec */, int32_t rows, int32_t d, void* stream);
+int vx_op_gemv(int32_t prec, const void* W, const float* bias, const float* x, float* y, int32_t N, int32_t K,
+               int32_t relu, void* stream);
+int vx_op_gemm(int32_t prec, int32_t use_mfma, const void* A, const void* W, const float* bias, float* C_f32,
+               int32_t M, int32_t N, int32_t K, int32_t relu, void* stream);
+int vx_op_attention(int32_t prec, int32_t use_mfma, const void* qkv, void* out, int32_t rows, int32_t nhead,
+                    int32_t hd, int32_t text_len_for_ar_mask /* <0: no mask */, void* stream);
+int vx_op_sample(const float* logits, int32_t V, int32_t top_k, float temperature, const float* exp_noise,
+                 int32_t* out_token_argmax /* [2]: sampled, argmax */, void* stream);
+int vx_op_convert_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VALLEX_H */

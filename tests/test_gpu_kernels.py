@@ -1,0 +1,129 @@
+"""GPU: every HIP kernel, called through the C ABI (vx_op_*), against the torch op the oracle
+uses for the same step.  Integer/index outputs are compared bit-exactly; floating point within
+the tolerance written next to each check."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from valle_amd import engine
+
+    engine.load_library()
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return engine
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("rows,d", [(1, 1024), (273, 1024), (37, 256), (5, 128)])
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_layernorm(eng, rows, d, adaptive):
+    x, g, b = _rand(rows, d, seed=1, scale=3.0), 1 + 0.1 * _rand(d, seed=2), 0.1 * _rand(d, seed=3)
+    w, c = (1 + 0.1 * _rand(d, seed=4), 0.1 * _rand(d, seed=5)) if adaptive else (None, None)
+    ref = F.layer_norm(x, (d,), g, b, 1e-5)
+    if adaptive:
+        ref = w * ref + c
+    dev = lambda t: None if t is None else t.cuda()
+    out = eng.op_layernorm(dev(x), dev(g), dev(b), dev(w), dev(c), torch.float32).cpu()
+    assert (out - ref).abs().max() <= 2e-5  # fp32: differs from torch only in reduction order
+    outb = eng.op_layernorm(dev(x), dev(g), dev(b), dev(w), dev(c), torch.bfloat16).cpu().float()
+    assert (outb - ref).abs().max() <= 2 ** -7 * ref.abs().max()  # one bf16 rounding
+
+
+@pytest.mark.parametrize("N,K", [(3072, 1024), (1024, 4096), (1025, 1024), (4096, 1024), (768, 256), (1024, 256),
+                                 (384, 128), (128, 512), (1025, 128)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_gemv(eng, N, K, prec):
+    W, b, x = _rand(N, K, seed=1, scale=K ** -0.5), _rand(N, seed=2), _rand(K, seed=3)
+    Wd = W.cuda() if prec == "fp32" else W.cuda().to(torch.bfloat16)
+    Wr = W if prec == "fp32" else W.to(torch.bfloat16).float()  # same stored values, fp32 arithmetic
+    ref = F.linear(x.double(), Wr.double(), b.double()).float()
+    y = eng.op_gemv(Wd, b.cuda(), x.cuda()).cpu()
+    assert (y - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
+    yr = eng.op_gemv(Wd, b.cuda(), x.cuda(), relu=True).cpu()
+    assert (yr - ref.clamp_min(0)).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K", [(272, 3072, 1024), (1025, 1024, 4096), (100, 384, 128), (753, 1024, 1024), (65, 256, 256)])
+def test_gemm_fp32(eng, M, N, K):
+    A, W, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
+    ref = F.linear(A.double(), W.double(), b.double()).float()
+    out = eng.op_gemm(A.cuda(), W.cuda(), b.cuda()).cpu()
+    assert (out - ref).abs().max() <= 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(272, 3072, 1024), (1025, 1024, 4096), (100, 384, 128), (753, 1024, 1024), (128, 128, 64),
+                                   (1, 256, 256)])
+@pytest.mark.parametrize("mfma", [False, True])
+def test_gemm_bf16(eng, M, N, K, mfma):
+    A, W, b = _rand(M, K, seed=1).to(torch.bfloat16), _rand(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16), _rand(N, seed=3)
+    ref = F.linear(A.double(), W.double(), b.double()).float()  # exact products of the bf16 values
+    out = eng.op_gemm(A.cuda(), W.cuda(), b.cuda(), mfma=mfma).cpu()
+    assert (out - ref).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max()))  # fp32 accumulation order only
+    outr = eng.op_gemm(A.cuda(), W.cuda(), b.cuda(), relu=True, mfma=mfma).cpu()
+    assert (outr - ref.clamp_min(0)).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_mfma_gemm_layout_asymmetric(eng):
+    """A = I against an asymmetric W catches a transposed C write (cdna guide §3)."""
+    K = 128
+    A = torch.eye(K).to(torch.bfloat16)
+    W = (torch.arange(256 * K).reshape(256, K) % 251).float().to(torch.bfloat16)
+    out = eng.op_gemm(A.cuda(), W.cuda(), None, mfma=True).cpu()
+    assert torch.equal(out, W.float().t().contiguous())
+
+
+def _attn_ref(qkv, H, text_len):
+    N, d3 = qkv.shape
+    d = d3 // 3
+    q, k, v = qkv.double().chunk(3, -1)
+    sp = lambda t: t.reshape(N, H, d // H).transpose(0, 1)
+    s = sp(q) @ sp(k).transpose(1, 2) / (d // H) ** 0.5
+    if text_len >= 0:
+        m = torch.zeros(N, N, dtype=torch.bool)
+        m[:text_len, text_len:] = True
+        A = N - text_len
+        m[text_len:, text_len:] = torch.triu(torch.ones(A, A, dtype=torch.bool), 1)
+        s = s.masked_fill(m, float("-inf"))
+    return (torch.softmax(s, -1) @ sp(v)).transpose(0, 1).reshape(N, d).float()
+
+
+@pytest.mark.parametrize("N,H,text_len", [(272, 16, 47), (1025, 16, -1), (70, 4, 10), (63, 2, -1), (130, 4, 0), (9, 2, 9)])
+def test_attention_rows(eng, N, H, text_len):
+    qkv = _rand(N, 3 * H * 64, seed=5)
+    ref = _attn_ref(qkv, H, text_len)
+    out = eng.op_attention(qkv.cuda(), H, text_len).cpu()
+    assert (out - ref).abs().max() <= 2e-5
+    qb = qkv.to(torch.bfloat16)
+    refb = _attn_ref(qb.float(), H, text_len)
+    for mfma in (False, True):
+        outb = eng.op_attention(qb.cuda(), H, text_len, mfma=mfma).cpu().float()
+        assert (outb - refb).abs().max() <= 2e-2  # bf16 output rounding (|out| <~ 3) (+ bf16 P in the MFMA path)
+
+
+@pytest.mark.parametrize("top_k,temp", [(-100, 1.0), (1, 1.0), (10, 1.0), (50, 0.7), (1025, 1.3), (2000, 1.0), (3, 2.0)])
+def test_sampling_matches_oracle_bit_exact(eng, top_k, temp):
+    """Index selection (argmax, top-k set, sampled token) must equal the oracle's exactly."""
+    from oracle import valle_oracle as vo
+
+    for seed in range(12):
+        logits = _rand(1, 1025, seed=seed, scale=3.0)
+        if seed % 3 == 0:  # exact ties around the k-th value and at the maximum
+            logits[0, 5] = logits[0, 900] = logits[0].topk(10)[0][-1]
+            logits[0, 77] = logits[0].max()
+        g = torch.Generator().manual_seed(100 + seed)
+        q = torch.empty(1, 1025).exponential_(1, generator=g)
+        want = int(vo.topk_sampling(logits.clone(), top_k, temp, q))
+        got, am = eng.op_sample(logits[0].cuda(), top_k, temp, q[0].cuda())
+        assert am == int(torch.argmax(logits, -1))
+        assert got == want, (seed, top_k, temp)

@@ -1,0 +1,41 @@
+"""Build libvallex.so (HIP, gfx950 only) in-tree next to this file.
+
+    python vall-e_amd/csrc/build.py [--force]
+
+hipcc cross-compiles for gfx950 without a GPU; the resulting .so travels to the GPU box with the
+repo snapshot (it is git-ignored, not gpurun-ignored)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "libvallex.so")
+SRCS = ["engine.hip"]
+DEPS = SRCS + ["common.hpp", "ar_kernels.hpp", "rows_kernels.hpp", "mfma_kernels.hpp", "../../include/vallex.h", "build.py"]
+
+
+def stale() -> bool:
+    if not os.path.isfile(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
+           "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+           "-o", OUT] + [os.path.join(HERE, s) for s in SRCS]
+    if os.environ.get("VX_SAVE_TEMPS"):
+        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=HERE)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

@@ -1,0 +1,896 @@
+// libvallex.so — host side of the engine and the C ABI declared in include/vallex.h.
+// One engine = one model replica on one GPU: weights, KV cache, activation arena, a private
+// stream and the captured hipGraph of one AR decode step.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/vallex.h"
+#include "ar_kernels.hpp"
+#include "rows_kernels.hpp"
+#include "mfma_kernels.hpp"
+
+using namespace vx;
+
+// ------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPC(expr)                                                                                  \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) return fail(VX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                          \
+  } while (0)
+#define VXC(expr)               \
+  do {                          \
+    int r_ = (expr);            \
+    if (r_ != VX_OK) return r_; \
+  } while (0)
+
+extern "C" const char* vx_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------ engine state
+struct Tensor {
+  void* p = nullptr;
+  std::vector<int64_t> shape;
+  size_t numel = 0;
+  bool low = false;  // stored in the precision's matrix type (bf16 in VX_PREC_BF16)
+  bool set = false;
+};
+
+struct LayerW {
+  const void *in_w, *out_w, *w1, *w2;
+  const float *in_b, *out_b, *b1, *b2;
+  const float *n1_g, *n1_b, *n2_g, *n2_b;
+};
+
+constexpr int NSPLIT = 8;
+constexpr int POLL_CHUNK = 32;
+
+struct vx_engine {
+  vx_config cfg{};
+  bool bf16 = false;
+  size_t esz = 4;  // bytes per matrix / KV / GEMM-operand element
+  int num_cu = 256;
+  hipStream_t es = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t[6] = {};
+  hipEvent_t ev_poll[2] = {};
+  std::unordered_map<std::string, Tensor> w;
+  std::vector<std::string> keys;
+  bool finalized = false;
+  std::vector<LayerW> ar_l, nar_l;
+  // sine tables
+  float *pe_ar = nullptr, *pe_nar = nullptr;
+  int pe_rows = 0;
+  bool pe_ar_set = false, pe_nar_set = false;
+  // AR buffers
+  int ctx_max = 0;
+  float *ar_x = nullptr, *ar_q = nullptr, *ar_part = nullptr, *ar_f = nullptr, *ar_logits = nullptr;
+  void* kv = nullptr;  // [L][2][H][ctx_max][hd]
+  ArState* d_st = nullptr;
+  ArState* h_st = nullptr;  // pinned: [0] staging, [1..2] poll slots
+  int *d_tokens = nullptr, *d_sampled = nullptr, *d_argmax = nullptr;
+  float* d_noise = nullptr;
+  size_t noise_cap = 0;
+  long long* d_forced = nullptr;
+  size_t forced_cap = 0;
+  // row buffers
+  int n_max = 0;
+  float* X = nullptr;
+  void *Hn = nullptr, *QKV = nullptr, *ATT = nullptr, *FF = nullptr;
+  float *yemb = nullptr, *nar_logits = nullptr, *ada = nullptr;
+  long long *ids_text = nullptr, *ids_audio = nullptr, *ids_prompts = nullptr, *ids_samples = nullptr, *d_codes = nullptr;
+  // graph
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  // per-utterance state
+  int S = 0, P = 0, bos = 0;
+  bool prefilled = false, decoded = false;
+  int n_gen = 0, stop_reason = 0, n_pass = 0, last_T = 0, last_N = 0;
+  double t_prefill = 0, t_decode = 0, t_nar = 0, n_launch = 0;
+  std::vector<void*> allocs;
+};
+
+static int dalloc(vx_engine* e, void** p, size_t bytes) {
+  HIPC(hipMalloc(p, bytes ? bytes : 16));
+  e->allocs.push_back(*p);
+  return VX_OK;
+}
+template <typename T> static int dalloc_t(vx_engine* e, T** p, size_t n) { return dalloc(e, (void**)p, n * sizeof(T)); }
+
+static bool is_matrix_key(const std::string& k) {
+  auto ends = [&](const char* s) { size_t n = strlen(s); return k.size() >= n && k.compare(k.size() - n, n, s) == 0; };
+  if (k.find("project_layer") != std::string::npos) return false;
+  return ends("in_proj_weight") || ends("out_proj.weight") || ends("linear1.weight") || ends("linear2.weight") ||
+         k.rfind("ar_predict_layer", 0) == 0 || k.rfind("nar_predict_layers", 0) == 0;
+}
+
+// The reference's state_dict layout (valle.py:85-259); mirrored by valle_amd/weights.py.
+static void add_encoder_keys(vx_engine* e, const std::string& pre, int d, int L, bool adaptive) {
+  auto add = [&](const std::string& k, std::vector<int64_t> s) {
+    Tensor t; t.shape = s; t.numel = 1; for (auto v : s) t.numel *= (size_t)v;
+    t.low = e->bf16 && is_matrix_key(k);
+    e->w[k] = t; e->keys.push_back(k);
+  };
+  auto norm = [&](const std::string& p) {
+    if (adaptive) {
+      add(p + ".project_layer.weight", {2 * d, d}); add(p + ".project_layer.bias", {2 * d});
+      add(p + ".norm.weight", {d}); add(p + ".norm.bias", {d});
+    } else {
+      add(p + ".weight", {d}); add(p + ".bias", {d});
+    }
+  };
+  for (int i = 0; i < L; ++i) {
+    const std::string p = pre + ".layers." + std::to_string(i);
+    add(p + ".self_attn.in_proj_weight", {3 * d, d}); add(p + ".self_attn.in_proj_bias", {3 * d});
+    add(p + ".self_attn.out_proj.weight", {d, d}); add(p + ".self_attn.out_proj.bias", {d});
+    add(p + ".linear1.weight", {4 * d, d}); add(p + ".linear1.bias", {4 * d});
+    add(p + ".linear2.weight", {d, 4 * d}); add(p + ".linear2.bias", {d});
+    norm(p + ".norm1"); norm(p + ".norm2");
+  }
+  norm(pre + ".norm");
+}
+
+static void build_key_table(vx_engine* e) {
+  const vx_config& c = e->cfg;
+  const int d = c.d_model, dn = c.nar_d_model, Q = c.num_quantizers;
+  auto add = [&](const std::string& k, std::vector<int64_t> s) {
+    Tensor t; t.shape = s; t.numel = 1; for (auto v : s) t.numel *= (size_t)v;
+    t.low = e->bf16 && is_matrix_key(k);
+    e->w[k] = t; e->keys.push_back(k);
+  };
+  add("ar_text_embedding.word_embeddings.weight", {512, d});
+  add("nar_text_embedding.word_embeddings.weight", {512, dn});
+  add("ar_audio_embedding.word_embeddings.weight", {1025 + (c.prepend_bos ? 1 : 0), d});
+  add("ar_text_position.alpha", {1});
+  add("ar_audio_position.alpha", {1});
+  add_encoder_keys(e, "ar_decoder", d, c.num_layers, false);
+  add("ar_predict_layer.weight", {1025, d});
+  if (Q > 1) {
+    add("nar_audio_embeddings.0.word_embeddings.weight", {1025, dn});
+    for (int j = 1; j < Q; ++j) add("nar_audio_embeddings." + std::to_string(j) + ".word_embeddings.weight", {1024, dn});
+    add("nar_text_position.alpha", {1});
+    add("nar_audio_position.alpha", {1});
+    add_encoder_keys(e, "nar_decoder", dn, c.nar_num_layers, true);
+    for (int j = 0; j < Q - 1; ++j) add("nar_predict_layers." + std::to_string(j) + ".weight", {1024, dn});
+    for (int j = 0; j < Q - 1; ++j) add("nar_stage_embeddings." + std::to_string(j) + ".word_embeddings.weight", {1, dn});
+  }
+}
+
+static void host_sine_table(std::vector<float>& t, int rows, int d) {
+  t.assign((size_t)rows * d, 0.f);
+  for (int i = 0; i < d; i += 2) {
+    const float w = expf((float)i * -(logf(10000.0f) / (float)d));
+    for (int p = 0; p < rows; ++p) {
+      t[(size_t)p * d + i] = sinf((float)p * w);
+      if (i + 1 < d) t[(size_t)p * d + i + 1] = cosf((float)p * w);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ create/destroy
+extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
+  if (!cfg || !out) return fail(VX_ERR_ARG, "null argument");
+  if (cfg->struct_size != (int32_t)sizeof(vx_config)) return fail(VX_ERR_ARG, "vx_config.struct_size mismatch");
+  const vx_config& c = *cfg;
+  if (c.d_model <= 0 || c.nhead <= 0 || c.num_layers <= 0 || c.d_model % c.nhead)
+    return fail(VX_ERR_ARG, "bad d_model/nhead/num_layers");
+  if (c.num_quantizers < 1 || c.num_quantizers > 8) return fail(VX_ERR_ARG, "num_quantizers must be 1..8");
+  if (c.prefix_mode != 0 && c.prefix_mode != 1 && c.prefix_mode != 2 && c.prefix_mode != 4)
+    return fail(VX_ERR_ARG, "prefix_mode must be 0/1/2/4");
+  if (c.d_model / c.nhead != 64 || (c.num_quantizers > 1 && (c.nar_nhead <= 0 || c.nar_d_model / c.nar_nhead != 64)))
+    return fail(VX_ERR_UNSUPPORTED, "only head_dim 64 is built (d_model/nhead)");
+  if (c.d_model % 64 || c.d_model > 1024 || c.nar_d_model > 1024)
+    return fail(VX_ERR_UNSUPPORTED, "d_model must be a multiple of 64 and <= 1024");
+  if (c.max_text <= 0 || c.max_audio <= 0) return fail(VX_ERR_ARG, "capacities must be positive");
+  if (c.precision != VX_PREC_F32 && c.precision != VX_PREC_BF16) return fail(VX_ERR_ARG, "bad precision");
+
+  HIPC(hipSetDevice(c.device));
+  vx_engine* e = new vx_engine();
+  e->cfg = c;
+  e->bf16 = c.precision == VX_PREC_BF16;
+  e->esz = e->bf16 ? 2 : 4;
+  hipDeviceProp_t prop;
+  HIPC(hipGetDeviceProperties(&prop, c.device));
+  e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIPC(hipStreamCreateWithFlags(&e->es, hipStreamNonBlocking));
+  HIPC(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+  HIPC(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+  for (auto& ev : e->ev_t) HIPC(hipEventCreate(&ev));
+  for (auto& ev : e->ev_poll) HIPC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  build_key_table(e);
+
+  const int d = c.d_model, dn = c.num_quantizers > 1 ? c.nar_d_model : c.d_model;
+  const int dmax = d > dn ? d : dn;
+  e->ctx_max = c.max_text + c.max_audio;
+  e->n_max = e->ctx_max;
+  const int H = c.nhead, hd = d / H;
+  // sine tables (embedding.py:64 starts at 4000 rows and extends on demand)
+  e->pe_rows = e->ctx_max > 4000 ? e->ctx_max : 4000;
+  VXC(dalloc_t(e, &e->pe_ar, (size_t)e->pe_rows * d));
+  VXC(dalloc_t(e, &e->pe_nar, (size_t)e->pe_rows * dn));
+  // AR
+  VXC(dalloc_t(e, &e->ar_x, d));
+  VXC(dalloc_t(e, &e->ar_q, d));
+  VXC(dalloc_t(e, &e->ar_part, (size_t)H * NSPLIT * (2 + hd)));
+  VXC(dalloc_t(e, &e->ar_f, 4 * (size_t)d));
+  const size_t nlog = (c.flags & VX_FLAG_TRACE_LOGITS) ? (size_t)c.max_audio + 2 : 1;
+  VXC(dalloc_t(e, &e->ar_logits, nlog * AR_VOCAB));
+  VXC(dalloc(e, &e->kv, (size_t)c.num_layers * 2 * H * e->ctx_max * hd * e->esz));
+  VXC(dalloc_t(e, &e->d_st, 1));
+  HIPC(hipHostMalloc((void**)&e->h_st, 3 * sizeof(ArState)));
+  VXC(dalloc_t(e, &e->d_tokens, (size_t)c.max_audio + 2));
+  VXC(dalloc_t(e, &e->d_sampled, (size_t)c.max_audio + 2));
+  VXC(dalloc_t(e, &e->d_argmax, (size_t)c.max_audio + 2));
+  // rows
+  const size_t n = e->n_max;
+  VXC(dalloc_t(e, &e->X, n * dmax));
+  VXC(dalloc(e, &e->Hn, n * dmax * e->esz));
+  VXC(dalloc(e, &e->QKV, n * 3 * dmax * e->esz));
+  VXC(dalloc(e, &e->ATT, n * dmax * e->esz));
+  VXC(dalloc(e, &e->FF, n * 4 * dmax * e->esz));
+  VXC(dalloc_t(e, &e->yemb, (size_t)c.max_audio * dn));
+  VXC(dalloc_t(e, &e->nar_logits, (size_t)c.max_audio * 1024));
+  VXC(dalloc_t(e, &e->ids_text, (size_t)c.max_text));
+  VXC(dalloc_t(e, &e->ids_audio, (size_t)c.max_audio + 1));
+  VXC(dalloc_t(e, &e->ids_prompts, (size_t)c.max_audio * 8));
+  VXC(dalloc_t(e, &e->ids_samples, (size_t)c.max_audio));
+  VXC(dalloc_t(e, &e->d_codes, (size_t)c.max_audio * 8));
+  if (c.num_quantizers > 1)
+    VXC(dalloc_t(e, &e->ada, (size_t)(c.num_quantizers - 1) * (2 * c.nar_num_layers + 1) * 2 * dn));
+  // weights
+  for (auto& k : e->keys) {
+    Tensor& t = e->w[k];
+    VXC(dalloc(e, &t.p, t.numel * (t.low ? 2 : 4)));
+  }
+  *out = e;
+  return VX_OK;
+}
+
+extern "C" void vx_destroy(vx_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  if (e->es) (void)hipStreamSynchronize(e->es);
+  if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+  if (e->graph) (void)hipGraphDestroy(e->graph);
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->d_noise) (void)hipFree(e->d_noise);
+  if (e->d_forced) (void)hipFree(e->d_forced);
+  if (e->h_st) (void)hipHostFree(e->h_st);
+  for (auto& ev : e->ev_t) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : e->ev_poll) if (ev) (void)hipEventDestroy(ev);
+  if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+  if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+  if (e->es) (void)hipStreamDestroy(e->es);
+  delete e;
+}
+
+// ------------------------------------------------------------------------------ weights
+extern "C" int vx_set_weight(vx_engine* e, const char* key, const float* data, const int64_t* shape, int32_t ndim) {
+  if (!e || !key || !data || !shape) return fail(VX_ERR_ARG, "null argument");
+  HIPC(hipSetDevice(e->cfg.device));
+  auto it = e->w.find(key);
+  if (it == e->w.end()) return fail(VX_ERR_WEIGHTS, "unexpected key '%s'", key);
+  Tensor& t = it->second;
+  bool ok = (size_t)ndim == t.shape.size();
+  for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == t.shape[i];
+  if (!ok) return fail(VX_ERR_WEIGHTS, "shape mismatch for '%s'", key);
+  if (!t.low) {
+    HIPC(hipMemcpyAsync(t.p, data, t.numel * 4, hipMemcpyDefault, e->es));
+  } else {
+    float* stage = nullptr;
+    HIPC(hipMalloc((void**)&stage, t.numel * 4));
+    HIPC(hipMemcpyAsync(stage, data, t.numel * 4, hipMemcpyDefault, e->es));
+    convert_kernel<bf16><<<1024, 256, 0, e->es>>>(stage, (bf16*)t.p, t.numel);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(e->es));
+    HIPC(hipFree(stage));
+  }
+  HIPC(hipStreamSynchronize(e->es));  // `data` may be freed by the caller on return
+  t.set = true;
+  e->finalized = false;
+  return VX_OK;
+}
+
+extern "C" int vx_set_sine_table(vx_engine* e, int32_t which, const float* data, int64_t rows, int64_t dim) {
+  if (!e || !data) return fail(VX_ERR_ARG, "null argument");
+  HIPC(hipSetDevice(e->cfg.device));
+  const int d = which == 0 ? e->cfg.d_model : e->cfg.nar_d_model;
+  if (dim != d || rows < e->ctx_max) return fail(VX_ERR_ARG, "sine table must be (>= %d, %d)", e->ctx_max, d);
+  const int64_t r = rows < e->pe_rows ? rows : e->pe_rows;
+  HIPC(hipMemcpyAsync(which == 0 ? e->pe_ar : e->pe_nar, data, (size_t)r * d * 4, hipMemcpyDefault, e->es));
+  HIPC(hipStreamSynchronize(e->es));
+  (which == 0 ? e->pe_ar_set : e->pe_nar_set) = true;
+  return VX_OK;
+}
+
+template <typename T> static const T* W(vx_engine* e, const std::string& k) { return (const T*)e->w.at(k).p; }
+
+static void fill_layers(vx_engine* e, const std::string& pre, int L, bool adaptive, std::vector<LayerW>& out) {
+  out.resize(L);
+  for (int i = 0; i < L; ++i) {
+    const std::string p = pre + ".layers." + std::to_string(i);
+    LayerW& l = out[i];
+    l.in_w = W<void>(e, p + ".self_attn.in_proj_weight"); l.in_b = W<float>(e, p + ".self_attn.in_proj_bias");
+    l.out_w = W<void>(e, p + ".self_attn.out_proj.weight"); l.out_b = W<float>(e, p + ".self_attn.out_proj.bias");
+    l.w1 = W<void>(e, p + ".linear1.weight"); l.b1 = W<float>(e, p + ".linear1.bias");
+    l.w2 = W<void>(e, p + ".linear2.weight"); l.b2 = W<float>(e, p + ".linear2.bias");
+    const std::string s = adaptive ? ".norm" : "";
+    l.n1_g = W<float>(e, p + ".norm1" + s + ".weight"); l.n1_b = W<float>(e, p + ".norm1" + s + ".bias");
+    l.n2_g = W<float>(e, p + ".norm2" + s + ".weight"); l.n2_b = W<float>(e, p + ".norm2" + s + ".bias");
+  }
+}
+
+// AdaLN vectors: index (stage, site) -> 2*dn floats [w | b]; site = 2*layer + {0,1}, last = final norm
+static float* ada_vec(vx_engine* e, int stage, int site) {
+  const int sites = 2 * e->cfg.nar_num_layers + 1;
+  return e->ada + ((size_t)stage * sites + site) * 2 * e->cfg.nar_d_model;
+}
+
+extern "C" int vx_finalize_weights(vx_engine* e) {
+  if (!e) return fail(VX_ERR_ARG, "null engine");
+  HIPC(hipSetDevice(e->cfg.device));
+  for (auto& k : e->keys)
+    if (!e->w[k].set) return fail(VX_ERR_WEIGHTS, "missing key '%s' (strict load)", k.c_str());
+  const vx_config& c = e->cfg;
+  fill_layers(e, "ar_decoder", c.num_layers, false, e->ar_l);
+  std::vector<float> t;
+  if (!e->pe_ar_set) {
+    host_sine_table(t, e->pe_rows, c.d_model);
+    HIPC(hipMemcpy(e->pe_ar, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (c.num_quantizers > 1) {
+    if (!e->pe_nar_set) {
+      host_sine_table(t, e->pe_rows, c.nar_d_model);
+      HIPC(hipMemcpy(e->pe_nar, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    }
+    fill_layers(e, "nar_decoder", c.nar_num_layers, true, e->nar_l);
+    const int dn = c.nar_d_model, Ln = c.nar_num_layers;
+    for (int s = 0; s < c.num_quantizers - 1; ++s) {
+      const float* emb = W<float>(e, "nar_stage_embeddings." + std::to_string(s) + ".word_embeddings.weight");
+      for (int site = 0; site < 2 * Ln + 1; ++site) {
+        std::string p = site == 2 * Ln ? std::string("nar_decoder.norm")
+                                       : "nar_decoder.layers." + std::to_string(site / 2) + (site % 2 ? ".norm2" : ".norm1");
+        project_vec_kernel<<<(2 * dn + 3) / 4, 256, 0, e->es>>>(W<float>(e, p + ".project_layer.weight"),
+                                                                W<float>(e, p + ".project_layer.bias"), emb,
+                                                                ada_vec(e, s, site), 2 * dn, dn);
+      }
+    }
+    HIPC(hipGetLastError());
+  }
+  HIPC(hipStreamSynchronize(e->es));
+  e->finalized = true;
+  return VX_OK;
+}
+
+// ------------------------------------------------------------------------------ launch helpers
+template <typename WT, int KCH, int RPW>
+static void launch_gemv_inst(const GemvArgs& a, int grid, hipStream_t s) {
+  const size_t lds = (size_t)(((a.K + 3) & ~3) + 8) * sizeof(float);
+  gemv_kernel<WT, KCH, RPW><<<grid, 256, lds, s>>>(a);
+}
+
+template <typename WT> static int launch_gemv_t(const GemvArgs& a, int num_cu, hipStream_t s) {
+  constexpr int VEC = Vec16<WT>::N;
+  if (a.K % VEC || a.K > 4096 || a.K % 4) return fail(VX_ERR_UNSUPPORTED, "gemv: K=%d unsupported", a.K);
+  const int need_kch = (a.K + 64 * VEC - 1) / (64 * VEC);
+  int kch = 1;
+  while (kch < need_kch) kch <<= 1;
+  if (kch > 16) return fail(VX_ERR_UNSUPPORTED, "gemv: K=%d too large", a.K);
+  int grid = num_cu;
+  if ((a.N + 3) / 4 < grid) grid = (a.N + 3) / 4;
+  const int need_rpw = (a.N + grid * 4 - 1) / (grid * 4);
+  int rpw = need_rpw >= 3 ? 4 : need_rpw;
+  while (rpw * kch > 16 && rpw > 1) rpw >>= 1;
+#define GV(KC, RP) if (kch == KC && rpw == RP) { launch_gemv_inst<WT, KC, RP>(a, grid, s); return VX_OK; }
+  GV(1, 1) GV(1, 2) GV(1, 4) GV(2, 1) GV(2, 2) GV(2, 4) GV(4, 1) GV(4, 2) GV(4, 4) GV(8, 1) GV(8, 2) GV(16, 1)
+#undef GV
+  return fail(VX_ERR_UNSUPPORTED, "gemv: no instance for kch=%d rpw=%d", kch, rpw);
+}
+
+static int launch_gemv(bool bf, const GemvArgs& a, int num_cu, hipStream_t s) {
+  return bf ? launch_gemv_t<bf16>(a, num_cu, s) : launch_gemv_t<float>(a, num_cu, s);
+}
+
+template <typename T>
+static int gemm_rows_t(bool mfma, const T* A, const T* Wt, const float* bias, void* C, int M, int N, int K, int epi,
+                       bool out_f32, hipStream_t s) {
+  if constexpr (std::is_same<T, bf16>::value) {
+    if (mfma) return mfma_gemm_dispatch(A, Wt, bias, C, M, N, K, epi, out_f32, s);
+  }
+  dim3 grid((N + 63) / 64, (M + 63) / 64);
+  if (epi == GE_RESID) gemm_simple_kernel<T, float, GE_RESID><<<grid, 256, 0, s>>>(A, Wt, bias, (float*)C, M, N, K);
+  else if (epi == GE_PLAIN) gemm_simple_kernel<T, float, GE_PLAIN><<<grid, 256, 0, s>>>(A, Wt, bias, (float*)C, M, N, K);
+  else if (epi == GE_BIAS && out_f32) gemm_simple_kernel<T, float, GE_BIAS><<<grid, 256, 0, s>>>(A, Wt, bias, (float*)C, M, N, K);
+  else if (epi == GE_RELU && out_f32) gemm_simple_kernel<T, float, GE_RELU><<<grid, 256, 0, s>>>(A, Wt, bias, (float*)C, M, N, K);
+  else if (epi == GE_BIAS) gemm_simple_kernel<T, T, GE_BIAS><<<grid, 256, 0, s>>>(A, Wt, bias, (T*)C, M, N, K);
+  else gemm_simple_kernel<T, T, GE_RELU><<<grid, 256, 0, s>>>(A, Wt, bias, (T*)C, M, N, K);
+  return VX_OK;
+}
+
+static bool use_mfma(const vx_engine* e) { return e->bf16 && !(e->cfg.flags & VX_FLAG_SIMPLE_ROWS); }
+
+static int gemm_rows(vx_engine* e, const void* A, const void* Wt, const float* bias, void* C, int M, int N, int K,
+                     int epi, bool out_f32) {
+  if (e->bf16) return gemm_rows_t<bf16>(use_mfma(e), (const bf16*)A, (const bf16*)Wt, bias, C, M, N, K, epi, out_f32, e->es);
+  return gemm_rows_t<float>(false, (const float*)A, (const float*)Wt, bias, C, M, N, K, epi, out_f32, e->es);
+}
+
+static int ln_rows(vx_engine* e, const float* x, const float* g, const float* b, const float* aw, const float* ab,
+                   void* out, int rows, int d) {
+  if (e->bf16) layernorm_rows_kernel<bf16><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (bf16*)out, rows, d);
+  else layernorm_rows_kernel<float><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (float*)out, rows, d);
+  return VX_OK;
+}
+
+static int attn_rows(vx_engine* e, const void* qkv, void* out, int M, int d, int H, int text_len) {
+  const float scale = 1.0f / sqrtf(64.0f);
+  if (use_mfma(e)) return mfma_attn_dispatch((const bf16*)qkv, (bf16*)out, M, d, H, text_len, scale, e->es);
+  dim3 grid((M + 63) / 64, H);
+  if (e->bf16) attn_rows_simple_kernel<bf16, 64><<<grid, 256, 0, e->es>>>((const bf16*)qkv, (bf16*)out, M, d, text_len, scale);
+  else attn_rows_simple_kernel<float, 64><<<grid, 256, 0, e->es>>>((const float*)qkv, (float*)out, M, d, text_len, scale);
+  return VX_OK;
+}
+
+// One encoder stack over M rows held in e->X (valle.py:1035-1038 / 1125-1127).  `ada_stage` < 0:
+// plain LayerNorm (AR); otherwise the stage's AdaLN vectors.  If kv_layer0 is non-null the K/V
+// rows are also scattered into the decode cache.
+static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int d, int H, int text_len, int ada_stage,
+                     bool fill_cache) {
+  const size_t kv_layer = (size_t)2 * H * e->ctx_max * 64 * e->esz;
+  for (size_t li = 0; li < layers.size(); ++li) {
+    const LayerW& l = layers[li];
+    const float *aw1 = nullptr, *ab1 = nullptr, *aw2 = nullptr, *ab2 = nullptr;
+    if (ada_stage >= 0) {
+      aw1 = ada_vec(e, ada_stage, 2 * (int)li); ab1 = aw1 + d;
+      aw2 = ada_vec(e, ada_stage, 2 * (int)li + 1); ab2 = aw2 + d;
+    }
+    VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d));
+    VXC(gemm_rows(e, e->Hn, l.in_w, l.in_b, e->QKV, M, 3 * d, d, GE_BIAS, false));
+    if (fill_cache) {
+      char* kc = (char*)e->kv + li * kv_layer;
+      char* vc = kc + kv_layer / 2;
+      if (e->bf16) kv_scatter_kernel<bf16><<<M, 256, 0, e->es>>>((const bf16*)e->QKV, (bf16*)kc, (bf16*)vc, M, d, 64, e->ctx_max);
+      else kv_scatter_kernel<float><<<M, 256, 0, e->es>>>((const float*)e->QKV, (float*)kc, (float*)vc, M, d, 64, e->ctx_max);
+    }
+    VXC(attn_rows(e, e->QKV, e->ATT, M, d, H, text_len));
+    VXC(gemm_rows(e, e->ATT, l.out_w, l.out_b, e->X, M, d, d, GE_RESID, true));
+    VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn, M, d));
+    VXC(gemm_rows(e, e->Hn, l.w1, l.b1, e->FF, M, 4 * d, d, GE_RELU, false));
+    VXC(gemm_rows(e, e->FF, l.w2, l.b2, e->X, M, d, 4 * d, GE_RESID, true));
+  }
+  HIPC(hipGetLastError());
+  return VX_OK;
+}
+
+static int sync_in(vx_engine* e, void* stream) {
+  hipStream_t cs = (hipStream_t)stream;
+  if (cs == e->es) return VX_OK;
+  HIPC(hipEventRecord(e->ev_in, cs));
+  HIPC(hipStreamWaitEvent(e->es, e->ev_in, 0));
+  return VX_OK;
+}
+static int sync_out(vx_engine* e, void* stream) {
+  hipStream_t cs = (hipStream_t)stream;
+  if (cs == e->es) return VX_OK;
+  HIPC(hipEventRecord(e->ev_out, e->es));
+  HIPC(hipStreamWaitEvent(cs, e->ev_out, 0));
+  return VX_OK;
+}
+
+// ------------------------------------------------------------------------------ AR
+static int enqueue_head(vx_engine* e, hipStream_t s) {
+  const vx_config& c = e->cfg;
+  GemvArgs a{};
+  a.W = W<void>(e, "ar_predict_layer.weight");
+  a.bias = nullptr;
+  a.x = e->ar_x;
+  a.gamma = W<float>(e, "ar_decoder.norm.weight");
+  a.beta = W<float>(e, "ar_decoder.norm.bias");
+  a.y = e->ar_logits;
+  a.N = AR_VOCAB; a.K = c.d_model;
+  a.pro = PRO_LN; a.epi = EPI_LOGITS;
+  a.st = e->d_st;
+  return launch_gemv(e->bf16, a, e->num_cu, s);
+}
+
+extern "C" int vx_ar_prefill(vx_engine* e, const int64_t* text, int32_t S, const int64_t* prompt_cb0, int32_t P,
+                             void* stream) {
+  if (!e || !text || (!prompt_cb0 && P > 0)) return fail(VX_ERR_ARG, "null argument");
+  if (!e->finalized) return fail(VX_ERR_STATE, "weights not finalized");
+  if (S <= 0 || P < 0) return fail(VX_ERR_ARG, "S must be > 0 (valle.py:991), P >= 0");
+  const vx_config& c = e->cfg;
+  const int bos = c.prepend_bos ? 1 : 0, A = bos + P, M = S + A, d = c.d_model;
+  if (S > c.max_text || A + 1 > c.max_audio) return fail(VX_ERR_CAPACITY, "S=%d / P=%d exceed capacity", S, P);
+  if (A == 0) return fail(VX_ERR_ARG, "empty audio prefix needs prepend_bos");
+  HIPC(hipSetDevice(c.device));
+  VXC(sync_in(e, stream));
+  HIPC(hipEventRecord(e->ev_t[0], e->es));
+  HIPC(hipMemcpyAsync(e->ids_text, text, (size_t)S * 8, hipMemcpyDefault, e->es));
+  if (bos) {
+    const long long b = NUM_AUDIO_TOKENS + 1;  // valle.py:1006-1007
+    HIPC(hipMemcpyAsync(e->ids_audio, &b, 8, hipMemcpyHostToDevice, e->es));
+  }
+  if (P) HIPC(hipMemcpyAsync(e->ids_audio + bos, prompt_cb0, (size_t)P * 8, hipMemcpyDefault, e->es));
+  embed_pos_kernel<<<S, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "ar_text_embedding.word_embeddings.weight"), d,
+                                         W<float>(e, "ar_text_position.alpha"), e->pe_ar, 0, e->X, S);
+  embed_pos_kernel<<<A, 256, 0, e->es>>>(e->ids_audio, 1, 0, W<float>(e, "ar_audio_embedding.word_embeddings.weight"), d,
+                                         W<float>(e, "ar_audio_position.alpha"), e->pe_ar, 0, e->X + (size_t)S * d, A);
+  VXC(run_stack(e, e->ar_l, M, d, c.nhead, S, -1, true));
+  HIPC(hipMemcpyAsync(e->ar_x, e->X + (size_t)(M - 1) * d, (size_t)d * 4, hipMemcpyDeviceToDevice, e->es));
+  // decode state as of "pass 0 computed"
+  ArState& st = e->h_st[0];
+  memset(&st, 0, sizeof st);
+  st.S = S; st.bos = bos; st.P = P; st.row = M - 1; st.pass = 0;
+  st.temperature = 1.0f; st.max_new = -1;
+  st.trace_logits = (c.flags & VX_FLAG_TRACE_LOGITS) ? 1 : 0;
+  HIPC(hipMemcpyAsync(e->d_st, &st, sizeof st, hipMemcpyHostToDevice, e->es));
+  VXC(enqueue_head(e, e->es));
+  HIPC(hipGetLastError());
+  HIPC(hipEventRecord(e->ev_t[1], e->es));
+  HIPC(hipStreamSynchronize(e->es));  // h_st[0] staging is reused by decode
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, e->ev_t[0], e->ev_t[1]));
+  e->t_prefill = ms;
+  e->S = S; e->P = P; e->bos = bos;
+  e->prefilled = true; e->decoded = false;
+  e->n_gen = 0; e->n_pass = 1; e->stop_reason = 0;
+  VXC(sync_out(e, stream));
+  return VX_OK;
+}
+
+// One decode step: sample from the newest logits, append, run the 12-layer stack on the new
+// token, produce the next logits.  Every kernel reads its position from e->d_st, so the same
+// launch sequence (captured once as a hipGraph) serves every pass.
+static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
+  const vx_config& c = e->cfg;
+  const int d = c.d_model, H = c.nhead, hd = 64;
+  SampleArgs sa{};
+  sa.logits = e->ar_logits; sa.V = AR_VOCAB; sa.st = e->d_st;
+  sa.tokens = e->d_tokens; sa.sampled = e->d_sampled; sa.argmaxes = e->d_argmax;
+  sa.emb = W<float>(e, "ar_audio_embedding.word_embeddings.weight");
+  sa.alpha = W<float>(e, "ar_audio_position.alpha");
+  sa.pe = e->pe_ar; sa.x = e->ar_x; sa.d = d;
+  sample_embed_kernel<<<1, 1024, 0, s>>>(sa);
+  const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd * e->esz;
+  const float scale = 1.0f / sqrtf((float)hd);
+  for (int li = 0; li < c.num_layers; ++li) {
+    const LayerW& l = e->ar_l[li];
+    char* kc = (char*)e->kv + (size_t)li * kv_layer;
+    char* vc = kc + kv_layer / 2;
+    GemvArgs a{};
+    a.st = e->d_st; a.d = d; a.hd = hd; a.ctx_max = e->ctx_max; a.nhead = H; a.nsplit = NSPLIT;
+    // qkv = in_proj(LN1(x)); k,v appended to the cache (transformer.py:297-301)
+    a.W = l.in_w; a.bias = l.in_b; a.x = e->ar_x; a.gamma = l.n1_g; a.beta = l.n1_b;
+    a.N = 3 * d; a.K = d; a.pro = PRO_LN; a.epi = EPI_QKV; a.q = e->ar_q; a.kcache = kc; a.vcache = vc;
+    VXC(launch_gemv(e->bf16, a, e->num_cu, s));
+    if (e->bf16) attn_decode_kernel<bf16, 64><<<H * NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, NSPLIT, scale);
+    else attn_decode_kernel<float, 64><<<H * NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, NSPLIT, scale);
+    // x += out_proj(attn)
+    GemvArgs o{};
+    o.st = e->d_st; o.hd = hd; o.nhead = H; o.nsplit = NSPLIT;
+    o.W = l.out_w; o.bias = l.out_b; o.part = e->ar_part; o.y = e->ar_x; o.N = d; o.K = d; o.pro = PRO_ATTN; o.epi = EPI_RESID;
+    VXC(launch_gemv(e->bf16, o, e->num_cu, s));
+    // f = relu(linear1(LN2(x)))
+    GemvArgs f{};
+    f.st = e->d_st;
+    f.W = l.w1; f.bias = l.b1; f.x = e->ar_x; f.gamma = l.n2_g; f.beta = l.n2_b; f.y = e->ar_f;
+    f.N = 4 * d; f.K = d; f.pro = PRO_LN; f.epi = EPI_RELU;
+    VXC(launch_gemv(e->bf16, f, e->num_cu, s));
+    // x += linear2(f)
+    GemvArgs g{};
+    g.st = e->d_st;
+    g.W = l.w2; g.bias = l.b2; g.x = e->ar_f; g.y = e->ar_x; g.N = d; g.K = 4 * d; g.pro = PRO_COPY; g.epi = EPI_RESID;
+    VXC(launch_gemv(e->bf16, g, e->num_cu, s));
+  }
+  VXC(enqueue_head(e, s));
+  return VX_OK;
+}
+
+extern "C" int vx_ar_decode(vx_engine* e, const vx_decode_params* p, void* stream) {
+  if (!e || !p) return fail(VX_ERR_ARG, "null argument");
+  if (p->struct_size != (int32_t)sizeof(vx_decode_params)) return fail(VX_ERR_ARG, "vx_decode_params.struct_size mismatch");
+  if (!e->prefilled || e->decoded) return fail(VX_ERR_STATE, "vx_ar_decode needs a fresh vx_ar_prefill");
+  if (!(p->temperature > 0.f)) return fail(VX_ERR_ARG, "temperature must be > 0");
+  const vx_config& c = e->cfg;
+  HIPC(hipSetDevice(c.device));
+  // upper bound on appended tokens (valle.py:1047: stops once bos + n_gen > 16 S)
+  long long max_tok = 16LL * e->S + 1 - e->bos;
+  if (p->forced) max_tok = p->n_forced;
+  else if (p->max_new_tokens >= 0 && p->max_new_tokens < max_tok) max_tok = p->max_new_tokens;
+  if (e->bos + e->P + max_tok > c.max_audio) return fail(VX_ERR_CAPACITY, "need %lld audio rows, capacity %d", e->bos + e->P + max_tok, c.max_audio);
+  VXC(sync_in(e, stream));
+  if (p->exp_noise) {
+    if (p->noise_rows <= 0) return fail(VX_ERR_ARG, "noise_rows must be > 0");
+    const size_t need = (size_t)p->noise_rows * AR_VOCAB;
+    if (need > e->noise_cap) {
+      if (e->d_noise) HIPC(hipFree(e->d_noise));
+      HIPC(hipMalloc((void**)&e->d_noise, need * 4));
+      e->noise_cap = need;
+    }
+    HIPC(hipMemcpyAsync(e->d_noise, p->exp_noise, need * 4, hipMemcpyDefault, e->es));
+  }
+  if (p->forced && p->n_forced > 0) {
+    if ((size_t)p->n_forced > e->forced_cap) {
+      if (e->d_forced) HIPC(hipFree(e->d_forced));
+      HIPC(hipMalloc((void**)&e->d_forced, (size_t)p->n_forced * 8));
+      e->forced_cap = p->n_forced;
+    }
+    HIPC(hipMemcpyAsync(e->d_forced, p->forced, (size_t)p->n_forced * 8, hipMemcpyDefault, e->es));
+  }
+  ArState& st = e->h_st[0];
+  st.top_k = p->top_k; st.temperature = p->temperature; st.max_new = p->max_new_tokens;
+  st.exp_noise = p->exp_noise ? e->d_noise : nullptr;
+  st.noise_rows = p->noise_rows; st.seed = p->seed;
+  st.forced = p->forced ? (p->n_forced > 0 ? e->d_forced : (const long long*)e->d_tokens) : nullptr;
+  st.n_forced = p->forced ? p->n_forced : 0;
+  HIPC(hipMemcpyAsync(e->d_st, &st, sizeof st, hipMemcpyHostToDevice, e->es));
+
+  const bool graph = !(c.flags & VX_FLAG_NO_GRAPH);
+  if (graph && !e->gexec) {
+    HIPC(hipStreamBeginCapture(e->es, hipStreamCaptureModeThreadLocal));
+    int r = enqueue_ar_step(e, e->es);
+    hipError_t ce = hipStreamEndCapture(e->es, &e->graph);
+    if (r != VX_OK) return r;
+    HIPC(ce);
+    HIPC(hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
+  }
+  HIPC(hipEventRecord(e->ev_t[2], e->es));
+  // step j samples from logits j and appends token j+1; the step that appends the last
+  // admissible token also raises the stop flag, so max_tok launches suffice (teacher forcing
+  // needs one more to close the sequence); EOS can only end it earlier.
+  long long bound = max_tok + (p->forced ? 1 : 0);
+  if (bound < 1) bound = 1;
+  long long launched = 0;
+  int slot = 0;
+  bool done = false;
+  bool pending[2] = {false, false};
+  while (!done) {
+    const long long n = (bound - launched) < POLL_CHUNK ? (bound - launched) : POLL_CHUNK;
+    for (long long i = 0; i < n; ++i) {
+      if (graph) HIPC(hipGraphLaunch(e->gexec, e->es));
+      else VXC(enqueue_ar_step(e, e->es));
+    }
+    launched += n;
+    HIPC(hipMemcpyAsync(&e->h_st[1 + slot], e->d_st, sizeof(ArState), hipMemcpyDeviceToHost, e->es));
+    HIPC(hipEventRecord(e->ev_poll[slot], e->es));
+    pending[slot] = true;
+    const int other = slot ^ 1;
+    // keep one chunk in flight while the previous one is inspected
+    if (pending[other]) {
+      HIPC(hipEventSynchronize(e->ev_poll[other]));
+      pending[other] = false;
+      if (e->h_st[1 + other].done) done = true;
+    }
+    if (!done && launched >= bound) {
+      HIPC(hipEventSynchronize(e->ev_poll[slot]));
+      pending[slot] = false;
+      if (!e->h_st[1 + slot].done) return fail(VX_ERR_STATE, "decode did not terminate within %lld steps", bound);
+      done = true;
+    }
+    slot = other;
+  }
+  HIPC(hipEventRecord(e->ev_t[3], e->es));
+  HIPC(hipMemcpyAsync(&e->h_st[1], e->d_st, sizeof(ArState), hipMemcpyDeviceToHost, e->es));
+  HIPC(hipStreamSynchronize(e->es));
+  HIPC(hipGetLastError());
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, e->ev_t[2], e->ev_t[3]));
+  e->t_decode = ms;
+  e->n_launch = (double)launched;
+  e->n_gen = e->h_st[1].n_gen;
+  e->stop_reason = e->h_st[1].stop_reason;
+  e->n_pass = e->h_st[1].pass + 1;
+  e->decoded = true;
+  VXC(sync_out(e, stream));
+  return VX_OK;
+}
+
+extern "C" int vx_ar_result(vx_engine* e, int64_t* tokens, int32_t capacity, int32_t* n_tokens, int32_t* stop_reason,
+                            int32_t* n_pass) {
+  if (!e) return fail(VX_ERR_ARG, "null engine");
+  if (!e->decoded) return fail(VX_ERR_STATE, "no finished decode");
+  HIPC(hipSetDevice(e->cfg.device));
+  if (n_tokens) *n_tokens = e->n_gen;
+  if (stop_reason) *stop_reason = e->stop_reason;
+  if (n_pass) *n_pass = e->n_pass;
+  if (tokens) {
+    if (capacity < e->n_gen) return fail(VX_ERR_CAPACITY, "token buffer too small (%d < %d)", capacity, e->n_gen);
+    std::vector<int> tmp(e->n_gen);
+    if (e->n_gen) HIPC(hipMemcpy(tmp.data(), e->d_tokens, (size_t)e->n_gen * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->n_gen; ++i) tokens[i] = tmp[i];
+  }
+  return VX_OK;
+}
+
+// ------------------------------------------------------------------------------ NAR
+extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
+                      const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream) {
+  if (!e || !text_nar || !ar_tokens || !codes_out || (P > 0 && !prompts)) return fail(VX_ERR_ARG, "null argument");
+  if (!e->finalized) return fail(VX_ERR_STATE, "weights not finalized");
+  const vx_config& c = e->cfg;
+  const int Q = c.num_quantizers;
+  if (S2 <= 0 || T <= 0 || P < 0) return fail(VX_ERR_ARG, "bad S2/P/T");
+  if (S2 > c.max_text || P + T > c.max_audio) return fail(VX_ERR_CAPACITY, "S2=%d P+T=%d exceed capacity", S2, P + T);
+  HIPC(hipSetDevice(c.device));
+  VXC(sync_in(e, stream));
+  HIPC(hipEventRecord(e->ev_t[4], e->es));
+  const int dn = c.nar_d_model, A = P + T, N = S2 + A;
+  // y = [prompt codebook 0 | AR tokens] (valle.py:1064-1066)
+  if (P) HIPC(hipMemcpyAsync(e->ids_prompts, prompts, (size_t)P * Q * 8, hipMemcpyDefault, e->es));
+  HIPC(hipMemcpyAsync(e->ids_samples, ar_tokens, (size_t)T * 8, hipMemcpyDefault, e->es));
+  copy_col_kernel<<<(T + 255) / 256, 256, 0, e->es>>>(e->ids_samples, e->d_codes, T, Q, 0);
+  if (Q > 1) {
+    HIPC(hipMemcpyAsync(e->ids_text, text_nar, (size_t)S2 * 8, hipMemcpyDefault, e->es));
+    auto emb = [&](int j) { return W<float>(e, "nar_audio_embeddings." + std::to_string(j) + ".word_embeddings.weight"); };
+    if (P) embed_accum_kernel<<<P, 256, 0, e->es>>>(e->ids_prompts, Q, 0, emb(0), dn, e->yemb, P, 1);
+    embed_accum_kernel<<<T, 256, 0, e->es>>>(e->ids_samples, 1, 0, emb(0), dn, e->yemb + (size_t)P * dn, T, 1);
+    if (c.prefix_mode != 0 && P)  // valle.py:1110-1113
+      for (int j = 1; j < Q; ++j) embed_accum_kernel<<<P, 256, 0, e->es>>>(e->ids_prompts, Q, j, emb(j), dn, e->yemb, P, 0);
+    const float* a_txt = W<float>(e, "nar_text_position.alpha");
+    const float* a_aud = W<float>(e, "nar_audio_position.alpha");
+    for (int i = 0; i < Q - 1; ++i) {
+      embed_pos_kernel<<<S2, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "nar_text_embedding.word_embeddings.weight"), dn,
+                                              a_txt, e->pe_nar, 0, e->X, S2);
+      add_pos_kernel<<<A, 256, 0, e->es>>>(e->yemb, dn, a_aud, e->pe_nar, 0, e->X + (size_t)S2 * dn, A);
+      VXC(run_stack(e, e->nar_l, N, dn, c.nar_nhead, -1, i, false));
+      // final AdaLN + predict layer on the T generated rows only (valle.py:1128)
+      const float* fw = ada_vec(e, i, 2 * c.nar_num_layers);
+      VXC(ln_rows(e, e->X + (size_t)(S2 + P) * dn, W<float>(e, "nar_decoder.norm.norm.weight"),
+                  W<float>(e, "nar_decoder.norm.norm.bias"), fw, fw + dn, e->Hn, T, dn));
+      VXC(gemm_rows(e, e->Hn, W<void>(e, "nar_predict_layers." + std::to_string(i) + ".weight"), nullptr, e->nar_logits,
+                    T, 1024, dn, GE_PLAIN, true));
+      argmax_rows_kernel<<<(T + 3) / 4, 256, 0, e->es>>>(e->nar_logits, 1024, T, e->ids_samples, e->d_codes, Q, i + 1);
+      if (i < Q - 2) {  // valle.py:1104-1108 / 1133-1134
+        if (c.prefix_mode == 0 && P)
+          embed_accum_kernel<<<P, 256, 0, e->es>>>(e->ids_prompts, Q, i + 1, emb(i + 1), dn, e->yemb, P, 0);
+        embed_accum_kernel<<<T, 256, 0, e->es>>>(e->ids_samples, 1, 0, emb(i + 1), dn, e->yemb + (size_t)P * dn, T, 0);
+      }
+    }
+  }
+  HIPC(hipGetLastError());
+  HIPC(hipEventRecord(e->ev_t[5], e->es));
+  HIPC(hipMemcpyAsync(codes_out, e->d_codes, (size_t)T * Q * 8, hipMemcpyDefault, e->es));
+  HIPC(hipStreamSynchronize(e->es));
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, e->ev_t[4], e->ev_t[5]));
+  e->t_nar = ms;
+  e->last_T = T; e->last_N = N;
+  VXC(sync_out(e, stream));
+  return VX_OK;
+}
+
+extern "C" int vx_get_timings(vx_engine* e, double* out, int32_t n) {
+  if (!e || !out) return fail(VX_ERR_ARG, "null argument");
+  const double v[5] = {e->t_prefill, e->t_decode, e->t_nar, (double)e->n_pass, e->n_launch};
+  for (int i = 0; i < n && i < 5; ++i) out[i] = v[i];
+  return VX_OK;
+}
+
+extern "C" int vx_read_buffer(vx_engine* e, const char* name, void* dst, int64_t off, int64_t nbytes) {
+  if (!e || !name || !dst) return fail(VX_ERR_ARG, "null argument");
+  HIPC(hipSetDevice(e->cfg.device));
+  HIPC(hipStreamSynchronize(e->es));
+  const std::string n = name;
+  const char* src = nullptr;
+  int64_t size = 0;
+  const bool trace = e->cfg.flags & VX_FLAG_TRACE_LOGITS;
+  if (n == "ar_logits") { src = (const char*)e->ar_logits; size = (int64_t)(trace ? e->n_pass : 1) * AR_VOCAB * 4; }
+  else if (n == "ar_sampled") { src = (const char*)e->d_sampled; size = (int64_t)e->n_pass * 4; }
+  else if (n == "ar_argmax") { src = (const char*)e->d_argmax; size = (int64_t)e->n_pass * 4; }
+  else if (n == "nar_logits") { src = (const char*)e->nar_logits; size = (int64_t)e->last_T * 1024 * 4; }
+  else if (n == "ar_x") { src = (const char*)e->ar_x; size = (int64_t)e->cfg.d_model * 4; }
+  else if (n == "nar_x") { src = (const char*)e->X; size = (int64_t)e->last_N * e->cfg.nar_d_model * 4; }
+  else return fail(VX_ERR_ARG, "unknown buffer '%s'", name);
+  if (off < 0 || nbytes < 0 || off + nbytes > size) return fail(VX_ERR_ARG, "read of '%s' out of range (%lld+%lld > %lld)", name, (long long)off, (long long)nbytes, (long long)size);
+  HIPC(hipMemcpy(dst, src + off, (size_t)nbytes, hipMemcpyDeviceToHost));
+  return VX_OK;
+}
+
+// ------------------------------------------------------------------------------ kernel-level ops
+extern "C" int vx_op_convert_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  convert_kernel<bf16><<<1024, 256, 0, (hipStream_t)stream>>>(src, (bf16*)dst, (size_t)n);
+  HIPC(hipGetLastError());
+  return VX_OK;
+}
+
+extern "C" int vx_op_layernorm(int32_t prec, const float* x, const float* gamma, const float* beta, const float* ada_w,
+                               const float* ada_b, void* out, int32_t rows, int32_t d, void* stream) {
+  if (d % 4 || d > 2048) return fail(VX_ERR_UNSUPPORTED, "layernorm: d=%d", d);
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == VX_PREC_BF16) layernorm_rows_kernel<bf16><<<(rows + 3) / 4, 256, 0, s>>>(x, gamma, beta, ada_w, ada_b, (bf16*)out, rows, d);
+  else layernorm_rows_kernel<float><<<(rows + 3) / 4, 256, 0, s>>>(x, gamma, beta, ada_w, ada_b, (float*)out, rows, d);
+  HIPC(hipGetLastError());
+  return VX_OK;
+}
+
+extern "C" int vx_op_gemv(int32_t prec, const void* Wp, const float* bias, const float* x, float* y, int32_t N, int32_t K,
+                          int32_t relu, void* stream) {
+  GemvArgs a{};
+  a.W = Wp; a.bias = bias; a.x = x; a.y = y; a.N = N; a.K = K;
+  a.pro = PRO_COPY; a.epi = relu ? EPI_RELU : (bias ? EPI_BIAS : EPI_PLAIN);
+  int dev = 0, cu = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+  VXC(launch_gemv(prec == VX_PREC_BF16, a, cu, (hipStream_t)stream));
+  HIPC(hipGetLastError());
+  return VX_OK;
+}
+
+extern "C" int vx_op_gemm(int32_t prec, int32_t mfma, const void* A, const void* Wp, const float* bias, float* C, int32_t M,
+                          int32_t N, int32_t K, int32_t relu, void* stream) {
+  const int epi = relu ? GE_RELU : (bias ? GE_BIAS : GE_PLAIN);
+  hipStream_t s = (hipStream_t)stream;
+  if (prec == VX_PREC_BF16) VXC(gemm_rows_t<bf16>(mfma != 0, (const bf16*)A, (const bf16*)Wp, bias, C, M, N, K, epi, true, s));
+  else {
+    if (mfma) return fail(VX_ERR_UNSUPPORTED, "MFMA GEMM is bf16 only");
+    VXC(gemm_rows_t<float>(false, (const float*)A, (const float*)Wp, bias, C, M, N, K, epi, true, s));
+  }
+  HIPC(hipGetLastError());
+  return VX_OK;
+}
+
+extern "C" int vx_op_attention(int32_t prec, int32_t mfma, const void* qkv, void* out, int32_t rows, int32_t nhead, int32_t hd,
+                               int32_t text_len, void* stream) {
+  if (hd != 64) return fail(VX_ERR_UNSUPPORTED, "attention: head_dim %d", hd);
+  hipStream_t s = (hipStream_t)stream;
+  const int d = nhead * hd;
+  const float scale = 1.0f / sqrtf((float)hd);
+  dim3 grid((rows + 63) / 64, nhead);
+  if (prec == VX_PREC_BF16) {
+    if (mfma) VXC(mfma_attn_dispatch((const bf16*)qkv, (bf16*)out, rows, d, nhead, text_len, scale, s));
+    else attn_rows_simple_kernel<bf16, 64><<<grid, 256, 0, s>>>((const bf16*)qkv, (bf16*)out, rows, d, text_len, scale);
+  } else {
+    if (mfma) return fail(VX_ERR_UNSUPPORTED, "MFMA attention is bf16 only");
+    attn_rows_simple_kernel<float, 64><<<grid, 256, 0, s>>>((const float*)qkv, (float*)out, rows, d, text_len, scale);
+  }
+  HIPC(hipGetLastError());
+  return VX_OK;
+}
+
+// Stand-alone sampling check: runs the step's sampling kernel on caller logits with a scratch
+// state (no stop-rule side effects are reported; out[0] = sampled index, out[1] = argmax).
+extern "C" int vx_op_sample(const float* logits, int32_t V, int32_t top_k, float temperature, const float* exp_noise,
+                            int32_t* out, void* stream) {
+  if (V < 2 || V > 2048) return fail(VX_ERR_UNSUPPORTED, "sample: V=%d", V);
+  hipStream_t s = (hipStream_t)stream;
+  ArState h{};
+  h.S = 1 << 20; h.top_k = top_k; h.temperature = temperature; h.max_new = -1;
+  h.exp_noise = exp_noise; h.noise_rows = 1; h.seed = 1;
+  ArState* dst = nullptr;
+  int* scratch = nullptr;
+  float* fz = nullptr;
+  HIPC(hipMalloc((void**)&dst, sizeof h));
+  HIPC(hipMalloc((void**)&scratch, 16 * sizeof(int)));
+  HIPC(hipMalloc((void**)&fz, 4096 * sizeof(float)));
+  HIPC(hipMemsetAsync(fz, 0, 4096 * sizeof(float), s));
+  HIPC(hipMemcpyAsync(dst, &h, sizeof h, hipMemcpyHostToDevice, s));
+  SampleArgs sa{};
+  sa.logits = logits; sa.V = V; sa.st = dst;
+  sa.tokens = scratch; sa.sampled = scratch + 4; sa.argmaxes = scratch + 8;
+  sa.emb = fz; sa.alpha = fz; sa.pe = fz; sa.x = fz + 2048; sa.d = 0;
+  sample_embed_kernel<<<1, 1024, 0, s>>>(sa);
+  HIPC(hipGetLastError());
+  int host[16];
+  HIPC(hipMemcpyAsync(host, scratch, sizeof host, hipMemcpyDeviceToHost, s));
+  HIPC(hipStreamSynchronize(s));
+  out[0] = host[4];
+  out[1] = host[8];
+  (void)hipFree(dst); (void)hipFree(scratch); (void)hipFree(fz);
+  return VX_OK;
+}

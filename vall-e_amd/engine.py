@@ -1,0 +1,265 @@
+"""ctypes binding of libvallex.so (the C ABI in include/vallex.h).
+
+There is deliberately no fallback: if the HIP library is missing or fails to load, importing
+the symbols raises, and every product entry point that needs the GPU fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvallex.so")
+
+VX_PREC_F32, VX_PREC_BF16 = 0, 1
+VX_FLAG_TRACE_LOGITS, VX_FLAG_NO_GRAPH, VX_FLAG_SIMPLE_ROWS = 1, 2, 4
+STOP_REASONS = {0: "none", 1: "eos_argmax", 2: "eos_sample", 3: "length", 4: "max_new"}
+
+
+class VxConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_size", "d_model", "nhead", "num_layers", "nar_d_model", "nar_nhead", "nar_num_layers",
+        "num_quantizers", "prefix_mode", "prepend_bos", "precision", "max_text", "max_audio", "device", "flags")]
+
+
+class VxDecodeParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("top_k", C.c_int32), ("temperature", C.c_float), ("max_new_tokens", C.c_int32),
+        ("exp_noise", C.c_void_p), ("noise_rows", C.c_int64), ("seed", C.c_uint64),
+        ("forced", C.c_void_p), ("n_forced", C.c_int32),
+    ]
+
+
+class VxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"vallex error {code}: {msg}")
+        self.code = code
+
+
+_lib: Optional[C.CDLL] = None
+
+_SIGS = {
+    "vx_last_error": (C.c_char_p, []),
+    "vx_create": (C.c_int, [C.POINTER(VxConfig), C.POINTER(C.c_void_p)]),
+    "vx_destroy": (None, [C.c_void_p]),
+    "vx_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
+    "vx_set_sine_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64]),
+    "vx_finalize_weights": (C.c_int, [C.c_void_p]),
+    "vx_ar_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "vx_ar_decode": (C.c_int, [C.c_void_p, C.POINTER(VxDecodeParams), C.c_void_p]),
+    "vx_ar_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "vx_nar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "vx_get_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32]),
+    "vx_read_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "vx_op_layernorm": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p]),
+    "vx_op_gemv": (C.c_int, [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "vx_op_gemm": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
+    "vx_op_attention": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
+    "vx_op_sample": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "vx_op_convert_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """Loads libvallex.so and attaches the prototypes.  Raises if the library is absent: build it
+    with ``python vall-e_amd/csrc/build.py`` (or ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f"{path} not built — run `python vall-e_amd/csrc/build.py`; there is no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(code: int):
+    if code != 0:
+        raise VxError(code, load_library().vx_last_error().decode())
+
+
+def _ptr(t) -> Optional[int]:
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        assert t.is_contiguous()
+        return t.data_ptr()
+    if isinstance(t, np.ndarray):
+        assert t.flags["C_CONTIGUOUS"]
+        return t.ctypes.data
+    raise TypeError(type(t))
+
+
+def current_stream_ptr(device) -> Optional[int]:
+    s = torch.cuda.current_stream(device).cuda_stream
+    return s or None
+
+
+class Engine:
+    """One model replica on one GPU (see include/vallex.h for the contract of each call)."""
+
+    def __init__(self, cfg, precision: str = "bf16", max_text: int = 256, max_audio: int = 2048, device: int = 0,
+                 trace_logits: bool = False, no_graph: bool = False, simple_rows: bool = False):
+        self.lib = load_library()
+        self.cfg = cfg
+        self.device = int(device)
+        self.precision = precision
+        c = VxConfig()
+        c.struct_size = C.sizeof(VxConfig)
+        c.d_model, c.nhead, c.num_layers = cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers
+        c.nar_d_model, c.nar_nhead, c.nar_num_layers = cfg.nar_dim, cfg.nar_nhead, cfg.nar_layers
+        c.num_quantizers, c.prefix_mode, c.prepend_bos = cfg.num_quantizers, cfg.prefix_mode, int(cfg.prepend_bos)
+        c.precision = {"fp32": VX_PREC_F32, "f32": VX_PREC_F32, "bf16": VX_PREC_BF16}[precision]
+        c.max_text, c.max_audio, c.device = max_text, max_audio, self.device
+        c.flags = (VX_FLAG_TRACE_LOGITS if trace_logits else 0) | (VX_FLAG_NO_GRAPH if no_graph else 0) | \
+                  (VX_FLAG_SIMPLE_ROWS if simple_rows else 0)
+        self.max_text, self.max_audio, self.trace_logits = max_text, max_audio, trace_logits
+        h = C.c_void_p()
+        _check(self.lib.vx_create(C.byref(c), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights -----------------------------------------------------------------------------
+    def load_state_dict(self, sd, sine_tables: bool = True):
+        from .weights import expected_keys, sine_table
+
+        keys = expected_keys(self.cfg)
+        for k, shape in keys.items():
+            t = sd[k].detach().to(torch.float32).contiguous()
+            assert tuple(t.shape) == tuple(shape), (k, tuple(t.shape), shape)
+            shp = (C.c_int64 * t.dim())(*t.shape)
+            _check(self.lib.vx_set_weight(self.h, k.encode(), _ptr(t), shp, t.dim()))
+        if sine_tables:
+            rows = max(4000, self.max_text + self.max_audio)
+            pe = sine_table(rows, self.cfg.decoder_dim)
+            _check(self.lib.vx_set_sine_table(self.h, 0, _ptr(pe), rows, self.cfg.decoder_dim))
+            if self.cfg.num_quantizers > 1:
+                pe = sine_table(rows, self.cfg.nar_dim)
+                _check(self.lib.vx_set_sine_table(self.h, 1, _ptr(pe), rows, self.cfg.nar_dim))
+        _check(self.lib.vx_finalize_weights(self.h))
+
+    # -- hot path ----------------------------------------------------------------------------
+    def ar_prefill(self, text: torch.Tensor, prompt_cb0: torch.Tensor, stream=None):
+        text = text.to(torch.int64).contiguous()
+        prompt_cb0 = prompt_cb0.to(torch.int64).contiguous()
+        self._keep = (text, prompt_cb0)
+        _check(self.lib.vx_ar_prefill(self.h, _ptr(text), text.numel(), _ptr(prompt_cb0), prompt_cb0.numel(), stream))
+
+    def ar_decode(self, top_k: int = -100, temperature: float = 1.0, exp_noise: Optional[torch.Tensor] = None,
+                  seed: int = 0, max_new_tokens: int = -1, forced: Optional[torch.Tensor] = None, stream=None):
+        p = VxDecodeParams()
+        p.struct_size = C.sizeof(VxDecodeParams)
+        p.top_k, p.temperature, p.max_new_tokens, p.seed = int(top_k), float(temperature), int(max_new_tokens), int(seed)
+        keep = []
+        if exp_noise is not None:
+            exp_noise = exp_noise.to(torch.float32).contiguous()
+            assert exp_noise.dim() == 2 and exp_noise.shape[1] == 1025
+            p.exp_noise, p.noise_rows = _ptr(exp_noise), exp_noise.shape[0]
+            keep.append(exp_noise)
+        if forced is not None:
+            forced = forced.to(torch.int64).contiguous()
+            p.forced, p.n_forced = (_ptr(forced) if forced.numel() else _ptr(torch.zeros(1, dtype=torch.int64))), forced.numel()
+            keep.append(forced)
+        _check(self.lib.vx_ar_decode(self.h, C.byref(p), stream))
+
+    def ar_result(self):
+        n, reason, npass = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(self.lib.vx_ar_result(self.h, None, 0, C.byref(n), C.byref(reason), C.byref(npass)))
+        toks = torch.empty(n.value, dtype=torch.int64)
+        _check(self.lib.vx_ar_result(self.h, _ptr(toks), n.value, C.byref(n), C.byref(reason), C.byref(npass)))
+        return toks, reason.value, npass.value
+
+    def nar(self, text_nar: torch.Tensor, prompts: torch.Tensor, ar_tokens: torch.Tensor, out_device=None, stream=None):
+        """prompts: (P, Q); returns codes (T, Q) int64 on ``out_device`` (default: prompts' device)."""
+        text_nar = text_nar.to(torch.int64).contiguous()
+        prompts = prompts.to(torch.int64).contiguous()
+        ar_tokens = ar_tokens.to(torch.int64).contiguous()
+        T, Q = ar_tokens.numel(), self.cfg.num_quantizers
+        out = torch.empty((T, Q), dtype=torch.int64, device=out_device if out_device is not None else prompts.device)
+        _check(self.lib.vx_nar(self.h, _ptr(text_nar), text_nar.numel(), _ptr(prompts), prompts.shape[0],
+                               _ptr(ar_tokens), T, _ptr(out), stream))
+        return out
+
+    def timings(self):
+        buf = (C.c_double * 5)()
+        _check(self.lib.vx_get_timings(self.h, buf, 5))
+        return dict(prefill_ms=buf[0], decode_ms=buf[1], nar_ms=buf[2], n_pass=int(buf[3]), launches=int(buf[4]))
+
+    def read(self, name: str, shape, dtype=torch.float32, offset_bytes: int = 0) -> torch.Tensor:
+        out = torch.empty(shape, dtype=dtype)
+        _check(self.lib.vx_read_buffer(self.h, name.encode(), _ptr(out), offset_bytes, out.numel() * out.element_size()))
+        return out
+
+
+# ---- kernel-level ops (parity tests call the HIP kernels through the same C ABI) -------------------
+def _prec(t_or_name) -> int:
+    if isinstance(t_or_name, str):
+        return VX_PREC_BF16 if t_or_name == "bf16" else VX_PREC_F32
+    return VX_PREC_BF16 if t_or_name.dtype == torch.bfloat16 else VX_PREC_F32
+
+
+def op_layernorm(x, gamma, beta, ada_w=None, ada_b=None, out_dtype=torch.float32):
+    lib = load_library()
+    rows, d = x.shape
+    out = torch.empty((rows, d), dtype=out_dtype, device=x.device)
+    _check(lib.vx_op_layernorm(_prec(out), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(ada_w), _ptr(ada_b), _ptr(out), rows, d,
+                               current_stream_ptr(x.device)))
+    return out
+
+
+def op_gemv(W, bias, x, relu=False):
+    lib = load_library()
+    N, K = W.shape
+    y = torch.empty(N, dtype=torch.float32, device=x.device)
+    _check(lib.vx_op_gemv(_prec(W), _ptr(W), _ptr(bias), _ptr(x), _ptr(y), N, K, int(relu), current_stream_ptr(x.device)))
+    return y
+
+
+def op_gemm(A, W, bias=None, relu=False, mfma=False):
+    lib = load_library()
+    M, K = A.shape
+    N = W.shape[0]
+    Cm = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    _check(lib.vx_op_gemm(_prec(A), int(mfma), _ptr(A), _ptr(W), _ptr(bias), _ptr(Cm), M, N, K, int(relu),
+                          current_stream_ptr(A.device)))
+    return Cm
+
+
+def op_attention(qkv, nhead, text_len=-1, mfma=False):
+    lib = load_library()
+    rows, d3 = qkv.shape
+    d = d3 // 3
+    out = torch.empty((rows, d), dtype=qkv.dtype, device=qkv.device)
+    _check(lib.vx_op_attention(_prec(qkv), int(mfma), _ptr(qkv), _ptr(out), rows, nhead, d // nhead, text_len,
+                               current_stream_ptr(qkv.device)))
+    return out
+
+
+def op_sample(logits, top_k, temperature, exp_noise):
+    lib = load_library()
+    out = (C.c_int32 * 2)()
+    _check(lib.vx_op_sample(_ptr(logits), logits.numel(), int(top_k), float(temperature), _ptr(exp_noise), out,
+                            current_stream_ptr(logits.device)))
+    return out[0], out[1]
