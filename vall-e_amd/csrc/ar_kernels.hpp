@@ -19,7 +19,7 @@ struct GemvArgs {
   const float* x;      // (K,) input vector [PRO_COPY, PRO_LN]
   const float* gamma;  // PRO_LN
   const float* beta;
-  const float* part;   // PRO_ATTN: (nhead, nsplit, 2 + hd) split-KV partials {m, l, o[hd]}
+  const float* part;   // PRO_ATTN: (nhead, nsplit, 4 + hd) split-KV partials {m, l, -, -, o[hd]}
   float* y;            // output vector / residual stream / logits base
   int N, K;
   int pro, epi;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       }
     }
   } else {  // PRO_ATTN: merge the nsplit partial softmaxes of every head (flash-decoding combine)
-    const int hd = a.hd, ns = a.nsplit, stride = 2 + hd;
+    const int hd = a.hd, ns = a.nsplit, stride = 4 + hd;  // 16-byte aligned o[]
     for (int k = tid * 4; k < K; k += 1024) {
       const int h = k / hd, c = k - h * hd;
       const float* p = a.part + (size_t)h * ns * stride;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         const float ms = p[s * stride];
         const float f = (ms == -INFINITY) ? 0.f : expf(ms - M);
         L += p[s * stride + 1] * f;
-        const float4 ov = *reinterpret_cast<const float4*>(p + s * stride + 2 + c);
+        const float4 ov = *reinterpret_cast<const float4*>(p + s * stride + 4 + c);
         o.x += ov.x * f; o.y += ov.y * f; o.z += ov.z * f; o.w += ov.w * f;
       }
       const float inv = 1.0f / L;
@@ -281,9 +281,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
       L += sm_l[w] * f;
       o += sm_o[w][tid] * f;
     }
-    float* p = part + (size_t)blockIdx.x * (2 + HD);
+    float* p = part + (size_t)blockIdx.x * (4 + HD);
     if (tid == 0) { p[0] = M; p[1] = L; }
-    p[2 + tid] = o;
+    p[4 + tid] = o;
   }
 }
 

@@ -227,7 +227,7 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   // AR
   VXC(dalloc_t(e, &e->ar_x, d));
   VXC(dalloc_t(e, &e->ar_q, d));
-  VXC(dalloc_t(e, &e->ar_part, (size_t)H * NSPLIT * (2 + hd)));
+  VXC(dalloc_t(e, &e->ar_part, (size_t)H * NSPLIT * (4 + hd)));
   VXC(dalloc_t(e, &e->ar_f, 4 * (size_t)d));
   const size_t nlog = (c.flags & VX_FLAG_TRACE_LOGITS) ? (size_t)c.max_audio + 2 : 1;
   VXC(dalloc_t(e, &e->ar_logits, nlog * AR_VOCAB));
@@ -523,13 +523,13 @@ extern "C" int vx_ar_prefill(vx_engine* e, const int64_t* text, int32_t S, const
   HIPC(hipEventRecord(e->ev_t[0], e->es));
   HIPC(hipMemcpyAsync(e->ids_text, text, (size_t)S * 8, hipMemcpyDefault, e->es));
   if (bos) {
-    const long long b = NUM_AUDIO_TOKENS + 1;  // valle.py:1006-1007
+    static const long long b = NUM_AUDIO_TOKENS + 1;  // valle.py:1006-1007
     HIPC(hipMemcpyAsync(e->ids_audio, &b, 8, hipMemcpyHostToDevice, e->es));
   }
   if (P) HIPC(hipMemcpyAsync(e->ids_audio + bos, prompt_cb0, (size_t)P * 8, hipMemcpyDefault, e->es));
-  embed_pos_kernel<<<S, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "ar_text_embedding.word_embeddings.weight"), d,
+  embed_pos_kernel<<<S, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "ar_text_embedding.word_embeddings.weight"), 512, d,
                                          W<float>(e, "ar_text_position.alpha"), e->pe_ar, 0, e->X, S);
-  embed_pos_kernel<<<A, 256, 0, e->es>>>(e->ids_audio, 1, 0, W<float>(e, "ar_audio_embedding.word_embeddings.weight"), d,
+  embed_pos_kernel<<<A, 256, 0, e->es>>>(e->ids_audio, 1, 0, W<float>(e, "ar_audio_embedding.word_embeddings.weight"), 1025 + bos, d,
                                          W<float>(e, "ar_audio_position.alpha"), e->pe_ar, 0, e->X + (size_t)S * d, A);
   VXC(run_stack(e, e->ar_l, M, d, c.nhead, S, -1, true));
   HIPC(hipMemcpyAsync(e->ar_x, e->X + (size_t)(M - 1) * d, (size_t)d * 4, hipMemcpyDeviceToDevice, e->es));
@@ -738,14 +738,14 @@ extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const i
   if (Q > 1) {
     HIPC(hipMemcpyAsync(e->ids_text, text_nar, (size_t)S2 * 8, hipMemcpyDefault, e->es));
     auto emb = [&](int j) { return W<float>(e, "nar_audio_embeddings." + std::to_string(j) + ".word_embeddings.weight"); };
-    if (P) embed_accum_kernel<<<P, 256, 0, e->es>>>(e->ids_prompts, Q, 0, emb(0), dn, e->yemb, P, 1);
-    embed_accum_kernel<<<T, 256, 0, e->es>>>(e->ids_samples, 1, 0, emb(0), dn, e->yemb + (size_t)P * dn, T, 1);
+    if (P) embed_accum_kernel<<<P, 256, 0, e->es>>>(e->ids_prompts, Q, 0, emb(0), 1025, dn, e->yemb, P, 1);
+    embed_accum_kernel<<<T, 256, 0, e->es>>>(e->ids_samples, 1, 0, emb(0), 1025, dn, e->yemb + (size_t)P * dn, T, 1);
     if (c.prefix_mode != 0 && P)  // valle.py:1110-1113
-      for (int j = 1; j < Q; ++j) embed_accum_kernel<<<P, 256, 0, e->es>>>(e->ids_prompts, Q, j, emb(j), dn, e->yemb, P, 0);
+      for (int j = 1; j < Q; ++j) embed_accum_kernel<<<P, 256, 0, e->es>>>(e->ids_prompts, Q, j, emb(j), 1024, dn, e->yemb, P, 0);
     const float* a_txt = W<float>(e, "nar_text_position.alpha");
     const float* a_aud = W<float>(e, "nar_audio_position.alpha");
     for (int i = 0; i < Q - 1; ++i) {
-      embed_pos_kernel<<<S2, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "nar_text_embedding.word_embeddings.weight"), dn,
+      embed_pos_kernel<<<S2, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "nar_text_embedding.word_embeddings.weight"), 512, dn,
                                               a_txt, e->pe_nar, 0, e->X, S2);
       add_pos_kernel<<<A, 256, 0, e->es>>>(e->yemb, dn, a_aud, e->pe_nar, 0, e->X + (size_t)S2 * dn, A);
       VXC(run_stack(e, e->nar_l, N, dn, c.nar_nhead, -1, i, false));
@@ -758,8 +758,8 @@ extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const i
       argmax_rows_kernel<<<(T + 3) / 4, 256, 0, e->es>>>(e->nar_logits, 1024, T, e->ids_samples, e->d_codes, Q, i + 1);
       if (i < Q - 2) {  // valle.py:1104-1108 / 1133-1134
         if (c.prefix_mode == 0 && P)
-          embed_accum_kernel<<<P, 256, 0, e->es>>>(e->ids_prompts, Q, i + 1, emb(i + 1), dn, e->yemb, P, 0);
-        embed_accum_kernel<<<T, 256, 0, e->es>>>(e->ids_samples, 1, 0, emb(i + 1), dn, e->yemb + (size_t)P * dn, T, 0);
+          embed_accum_kernel<<<P, 256, 0, e->es>>>(e->ids_prompts, Q, i + 1, emb(i + 1), 1024, dn, e->yemb, P, 0);
+        embed_accum_kernel<<<T, 256, 0, e->es>>>(e->ids_samples, 1, 0, emb(i + 1), 1024, dn, e->yemb + (size_t)P * dn, T, 0);
       }
     }
   }

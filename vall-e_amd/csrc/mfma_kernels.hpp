@@ -128,7 +128,15 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
   }
   dim3 grid((N + 127) / 128, (M + 127) / 128);
   const size_t lds = 65536;
-#define MG(E, F) mfma_gemm_kernel<E, F><<<grid, 256, lds, s>>>(A, W, bias, C, M, N, K)
+#define MG(E, F)                                                                                             \
+  do {                                                                                                       \
+    static bool attr_done = false;                                                                           \
+    if (!attr_done) {                                                                                        \
+      (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_done = true;                                                                                      \
+    }                                                                                                        \
+    mfma_gemm_kernel<E, F><<<grid, 256, lds, s>>>(A, W, bias, C, M, N, K);                                   \
+  } while (0)
   if (epi == GE_RESID) MG(GE_RESID, true);
   else if (epi == GE_PLAIN) MG(GE_PLAIN, true);
   else if (epi == GE_BIAS && out_f32) MG(GE_BIAS, true);

@@ -10,12 +10,14 @@ namespace vx {
 
 // out[r] = table[ids[r*stride+off]] * 1.0 + alpha * pe[pos0 + r]   (embedding.py:93-97)
 __global__ __launch_bounds__(256) void embed_pos_kernel(const long long* __restrict__ ids, int id_stride, int id_off,
-                                                        const float* __restrict__ table, int d,
+                                                        const float* __restrict__ table, int table_rows, int d,
                                                         const float* __restrict__ alpha, const float* __restrict__ pe,
                                                         int pos0, float* __restrict__ out, int rows) {
   const int r = blockIdx.x;
   if (r >= rows) return;
-  const long long id = ids[(size_t)r * id_stride + id_off];
+  // ids are validated by the host shim (IndexError like nn.Embedding); the clamp only keeps a
+  // bad id from a raw C-ABI caller inside the table
+  const long long id = min(max(ids[(size_t)r * id_stride + id_off], 0ll), (long long)table_rows - 1);
   const float al = alpha[0];
   for (int c = threadIdx.x; c < d; c += 256)
     out[(size_t)r * d + c] = __fadd_rn(table[(size_t)id * d + c], __fmul_rn(al, pe[(size_t)(pos0 + r) * d + c]));
@@ -34,11 +36,11 @@ __global__ __launch_bounds__(256) void add_pos_kernel(const float* __restrict__ 
 
 // acc[r] (=|+=) table[ids[r*stride+off]]   (valle.py:1064-1066, 1105-1113, 1134)
 __global__ __launch_bounds__(256) void embed_accum_kernel(const long long* __restrict__ ids, int id_stride, int id_off,
-                                                          const float* __restrict__ table, int d,
+                                                          const float* __restrict__ table, int table_rows, int d,
                                                           float* __restrict__ acc, int rows, int init) {
   const int r = blockIdx.x;
   if (r >= rows) return;
-  const long long id = ids[(size_t)r * id_stride + id_off];
+  const long long id = min(max(ids[(size_t)r * id_stride + id_off], 0ll), (long long)table_rows - 1);
   for (int c = threadIdx.x; c < d; c += 256) {
     const float e = table[(size_t)id * d + c];
     acc[(size_t)r * d + c] = init ? e : __fadd_rn(acc[(size_t)r * d + c], e);

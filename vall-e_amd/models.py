@@ -14,7 +14,7 @@ from typing import Optional
 
 import torch
 
-from .config import NUM_AUDIO_TOKENS, ModelConfig, add_model_arguments  # noqa: F401
+from .config import NUM_AUDIO_TOKENS, NUM_TEXT_TOKENS, ModelConfig, add_model_arguments  # noqa: F401
 from .weights import expected_keys, synthetic_state_dict, tied_keys
 
 _IncompatibleKeys = namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
@@ -125,6 +125,8 @@ class VALLE:
             raise RuntimeError(f"x must be one unpadded sequence: x {tuple(x.shape)} vs x_lens.max() {S}")
         eng = self.engine()
         Q, bos = self.num_quantizers, int(self.ar_audio_prepend_bos)
+        if int(x.min()) < 0 or int(x.max()) >= NUM_TEXT_TOKENS or int(y.min()) < 0 or int(y[..., :Q].max()) >= NUM_AUDIO_TOKENS:
+            raise IndexError("index out of range in self")  # what nn.Embedding raises in the reference
         text = x[0]
         prompts = y[0, :, :Q].contiguous()
         P = prompts.shape[0]
