@@ -154,6 +154,10 @@ int vx_op_sample(const float* logits, int32_t V, int32_t top_k, float temperatur
                  int32_t* out_token_argmax /* [2]: sampled, argmax */, void* stream);
 int vx_op_convert_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
 
+/* Measurement aid for DESIGN.md's launch-boundary budget: us per kernel of a dependent chain of
+ * n trivial kernels, out[0] replayed as a hipGraph, out[1] launched eagerly. */
+int vx_debug_launch_floor(int32_t n_kernels, int32_t grid, int32_t block, int32_t iters, double* out);
+
 #ifdef __cplusplus
 }
 #endif

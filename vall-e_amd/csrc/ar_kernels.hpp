@@ -1,10 +1,16 @@
 // Kernels of the batch-1 AR decode step (valle/models/valle.py:1012-1057 with a KV cache).
 //
-// The step is HBM-bound: 12 * d^2 weights per layer are streamed once per token.  Each GEMV
-// workgroup issues its 16-byte weight loads FIRST and only then computes the activation-side
-// prologue (LayerNorm / attention-split combine), so the HBM latency of the weight stream is
-// overlapped with the small dependent work (cdna_hip_programming.md §5 "GEMV / M<=16" row:
-// weights straight to VGPRs, deep unroll, late wait).
+// One token = 12 layers x {QKV GEMV, split-KV attention, out-proj GEMV, FFN1 GEMV, FFN2 GEMV}
+// + head GEMV + sampling = 62 dependent launches over 304 MB of bf16 weights, so the step is
+// bounded by HBM streaming plus one launch boundary per all-to-all dependency.  Each kernel is
+// built to have ONE memory round trip on its critical path:
+//   * every small activation-side load (x, gamma, beta, bias, residual, state) is issued first,
+//     the 16-byte weight loads right after; vmcnt retires in order, so the LayerNorm runs on the
+//     early loads while the weight stream is still in flight;
+//   * LayerNorm is recomputed per wave in registers (x is 4 KB, L2-resident) with DPP
+//     reductions: no LDS, no workgroup barrier in the GEMV (the attention-combine prologue of
+//     the out-projection is the one exception, one barrier);
+//   * weights go straight to VGPRs (GEMV / M<=16 row of cdna_hip_programming.md §5).
 #pragma once
 #include "common.hpp"
 
@@ -13,13 +19,16 @@ namespace vx {
 enum GemvPro { PRO_COPY = 0, PRO_LN = 1, PRO_ATTN = 2 };
 enum GemvEpi { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU = 2, EPI_RESID = 3, EPI_QKV = 4, EPI_LOGITS = 5 };
 
+constexpr int ATT_NSPLIT = 8;        // key splits per head in the decode attention
+constexpr int ATT_PSTRIDE = 4 + 64;  // floats per partial: {m, l, -, -, o[64]}
+
 struct GemvArgs {
   const void* W;       // (N, K) row-major, WT
   const float* bias;   // (N,) or null
   const float* x;      // (K,) input vector [PRO_COPY, PRO_LN]
   const float* gamma;  // PRO_LN
   const float* beta;
-  const float* part;   // PRO_ATTN: (nhead, nsplit, 4 + hd) split-KV partials {m, l, -, -, o[hd]}
+  const float* part;   // PRO_ATTN: (nhead, ATT_NSPLIT, ATT_PSTRIDE) split-KV partials
   float* y;            // output vector / residual stream / logits base
   int N, K;
   int pro, epi;
@@ -27,125 +36,157 @@ struct GemvArgs {
   float* q;            // (d,)
   void* kcache;        // this layer's K: (nhead, ctx_max, hd) WT
   void* vcache;
-  int d, hd, ctx_max, nhead, nsplit;
+  int d, hd, ctx_max, nhead;
   const ArState* st;
 };
 
-// y = W x (+epilogue).  One wave owns RPW rows at a time; a row is KCH 16-byte loads per lane.
-template <typename WT, int KCH, int RPW>
+// y = W x (+epilogue).  One wave owns RPW rows at a time; a row is KCH 16-byte loads per lane;
+// lane l holds x[(c*64 + l)*VEC .. +VEC) for chunk c.
+template <typename WT, int KCH, int RPW, int PRO>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   constexpr int VEC = Vec16<WT>::N;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int V4 = VEC / 4;
+  __shared__ __attribute__((aligned(16))) float xs[PRO == PRO_ATTN ? 1024 : 4];
   const int K = a.K, N = a.N;
-  const int Kpad = (K + 3) & ~3;
-  float* xs = smem;           // K floats
-  float* red = smem + Kpad;   // 8 floats scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nwaves = gridDim.x * 4;
   const WT* __restrict__ W = reinterpret_cast<const WT*>(a.W);
+  int g = blockIdx.x * 4 + wave;
 
-  // ---- prologue part A: issue the (tiny, L2-resident) activation loads first: vmcnt retires
-  // in order, so they must be older than the weight loads to be waited on separately.
-  float4 xv[4];
-  const int n4 = (K + 1023) >> 10;  // float4 per thread (K <= 4096)
-  if (a.pro != PRO_ATTN) {
+  // ---- (A) small loads, issued first.  Every load is unconditional on a clamped (in-range)
+  // address and masked afterwards: a predicated load would put an exec-masked branch and a
+  // vmcnt(0) in front of the weight stream.
+  float4 x4[KCH][V4], g4[KCH][V4], b4[KCH][V4];
+  bool kok[KCH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = (i * 256 + tid) * 4;
-      xv[i] = (i < n4 && k < K) ? *reinterpret_cast<const float4*>(a.x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < KCH; ++c) kok[c] = (c * 64 + lane) * VEC < K;
+  if (PRO != PRO_ATTN) {
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+      const int k = min((c * 64 + lane) * VEC, K - VEC);
+#pragma unroll
+      for (int j = 0; j < V4; ++j) {
+        x4[c][j] = *reinterpret_cast<const float4*>(a.x + k + 4 * j);
+        if (PRO == PRO_LN) {
+          g4[c][j] = *reinterpret_cast<const float4*>(a.gamma + k + 4 * j);
+          b4[c][j] = *reinterpret_cast<const float4*>(a.beta + k + 4 * j);
+        }
+      }
     }
+  }
+  // attention partials: thread t combines channels [4t, 4t+4) (K = d <= 1024)
+  float pm[ATT_NSPLIT], pl[ATT_NSPLIT];
+  float4 po[ATT_NSPLIT];
+  const int ka = min(tid * 4, K - 4);
+  if (PRO == PRO_ATTN) {
+    const int h = ka / a.hd, c = ka - h * a.hd;
+    const float* p = a.part + (size_t)h * ATT_NSPLIT * ATT_PSTRIDE;
+#pragma unroll
+    for (int s = 0; s < ATT_NSPLIT; ++s) {
+      const float2 ml = *reinterpret_cast<const float2*>(p + s * ATT_PSTRIDE);
+      pm[s] = ml.x; pl[s] = ml.y;
+      po[s] = *reinterpret_cast<const float4*>(p + s * ATT_PSTRIDE + 4 + c);
+    }
+  }
+  // epilogue operands of this wave's first row group: lane r owns row r (clamped, masked at the store)
+  const bool has_bias = a.bias != nullptr, has_res = a.epi == EPI_RESID;  // wave-uniform
+  float e_bias = 0.f, e_res = 0.f;
+  {
+    const int rc = min(g * RPW + min(lane, RPW - 1), N - 1);
+    if (has_bias) e_bias = a.bias[rc];
+    if (has_res) e_res = a.y[rc];
   }
   int st_row = 0, st_pass = 0, st_trace = 0, st_done = 0;
   if (a.st) { st_row = a.st->row; st_pass = a.st->pass; st_trace = a.st->trace_logits; st_done = a.st->done; }
 
-  // ---- weight loads of this wave's first row group
+  // ---- (B) weight stream of the first row group (rows/k clamped; x is zero where k >= K) ----
   uint4 w[RPW][KCH];
-  int g = blockIdx.x * 4 + wave;
   auto issue = [&](int grp) {
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-      const int row = grp * RPW + r;
+      const int row = min(grp * RPW + r, N - 1);
 #pragma unroll
       for (int c = 0; c < KCH; ++c) {
-        const int k = (c * 64 + lane) * VEC;
-        w[r][c] = (row < N && k < K) ? ld16(W + (size_t)row * K + k) : make_uint4(0u, 0u, 0u, 0u);
+        const int k = min((c * 64 + lane) * VEC, K - VEC);
+        w[r][c] = ld16(W + (size_t)row * K + k);
       }
     }
   };
   issue(g);
+  // pin the weight loads HERE: without this the scheduler sinks them below the prologue, next to
+  // their first use, and the HBM round trip is serialised behind the LayerNorm
+  __builtin_amdgcn_sched_barrier(0);
 
-  // ---- prologue part B: build the input vector in LDS
-  if (a.pro == PRO_COPY) {
+  // ---- (C) activation prologue in registers ---------------------------------------------------
+  float xr[KCH][VEC];
+  if (PRO == PRO_ATTN) {
+    {  // flash-decoding combine of the ATT_NSPLIT partial softmaxes
+      float M = pm[0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = (i * 256 + tid) * 4;
-      if (i < n4 && k < K) *reinterpret_cast<float4*>(xs + k) = xv[i];
-    }
-  } else if (a.pro == PRO_LN) {
-    // F.layer_norm over K channels (modules/transformer.py:57-74), two-pass in registers
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
-    const float mean = block_sum<4>(s, red) / (float)K;
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = (i * 256 + tid) * 4;
-      if (i < n4 && k < K) {
-        const float d0 = xv[i].x - mean, d1 = xv[i].y - mean, d2 = xv[i].z - mean, d3 = xv[i].w - mean;
-        ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-      }
-    }
-    const float var = block_sum<4>(ss, red) / (float)K;
-    const float rstd = 1.0f / sqrtf(var + LN_EPS);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = (i * 256 + tid) * 4;
-      if (i < n4 && k < K) {
-        const float4 gm = *reinterpret_cast<const float4*>(a.gamma + k);
-        const float4 bt = *reinterpret_cast<const float4*>(a.beta + k);
-        float4 o;
-        o.x = (xv[i].x - mean) * rstd * gm.x + bt.x;
-        o.y = (xv[i].y - mean) * rstd * gm.y + bt.y;
-        o.z = (xv[i].z - mean) * rstd * gm.z + bt.z;
-        o.w = (xv[i].w - mean) * rstd * gm.w + bt.w;
-        *reinterpret_cast<float4*>(xs + k) = o;
-      }
-    }
-  } else {  // PRO_ATTN: merge the nsplit partial softmaxes of every head (flash-decoding combine)
-    const int hd = a.hd, ns = a.nsplit, stride = 4 + hd;  // 16-byte aligned o[]
-    for (int k = tid * 4; k < K; k += 1024) {
-      const int h = k / hd, c = k - h * hd;
-      const float* p = a.part + (size_t)h * ns * stride;
-      float M = -INFINITY;
-      for (int s = 0; s < ns; ++s) M = fmaxf(M, p[s * stride]);
+      for (int s = 1; s < ATT_NSPLIT; ++s) M = fmaxf(M, pm[s]);
       float L = 0.f;
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s = 0; s < ns; ++s) {
-        const float ms = p[s * stride];
-        const float f = (ms == -INFINITY) ? 0.f : expf(ms - M);
-        L += p[s * stride + 1] * f;
-        const float4 ov = *reinterpret_cast<const float4*>(p + s * stride + 4 + c);
-        o.x += ov.x * f; o.y += ov.y * f; o.z += ov.z * f; o.w += ov.w * f;
+#pragma unroll
+      for (int s = 0; s < ATT_NSPLIT; ++s) {
+        const float f = (pm[s] == -INFINITY) ? 0.f : expf(pm[s] - M);
+        L += pl[s] * f;
+        o.x += po[s].x * f; o.y += po[s].y * f; o.z += po[s].z * f; o.w += po[s].w * f;
       }
       const float inv = 1.0f / L;
-      *reinterpret_cast<float4*>(xs + k) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+      // threads past K recompute the last quad and store the same values (benign)
+      *reinterpret_cast<float4*>(xs + ka) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+      const int k2 = min((c * 64 + lane) * VEC, K - VEC);
+#pragma unroll
+      for (int j = 0; j < V4; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(xs + k2 + 4 * j);
+        xr[c][4 * j] = kok[c] ? t.x : 0.f; xr[c][4 * j + 1] = kok[c] ? t.y : 0.f;
+        xr[c][4 * j + 2] = kok[c] ? t.z : 0.f; xr[c][4 * j + 3] = kok[c] ? t.w : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < KCH; ++c)
+#pragma unroll
+      for (int j = 0; j < V4; ++j) {
+        xr[c][4 * j] = kok[c] ? x4[c][j].x : 0.f; xr[c][4 * j + 1] = kok[c] ? x4[c][j].y : 0.f;
+        xr[c][4 * j + 2] = kok[c] ? x4[c][j].z : 0.f; xr[c][4 * j + 3] = kok[c] ? x4[c][j].w : 0.f;
+      }
+    if (PRO == PRO_LN) {  // F.layer_norm (modules/transformer.py:57-74), two-pass, whole row in this wave
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < KCH; ++c)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s += xr[c][j];  // out-of-range lanes hold zeros
+      const float mean = wave_sum_dpp(s) / (float)K;
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < KCH; ++c) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float dv = xr[c][j] - mean;
+          ss += kok[c] ? dv * dv : 0.f;
+        }
+      }
+      const float rstd = 1.0f / sqrtf(wave_sum_dpp(ss) / (float)K + LN_EPS);
+#pragma unroll
+      for (int c = 0; c < KCH; ++c)
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+          const float o0 = (xr[c][4 * j] - mean) * rstd * g4[c][j].x + b4[c][j].x;
+          const float o1 = (xr[c][4 * j + 1] - mean) * rstd * g4[c][j].y + b4[c][j].y;
+          const float o2 = (xr[c][4 * j + 2] - mean) * rstd * g4[c][j].z + b4[c][j].z;
+          const float o3 = (xr[c][4 * j + 3] - mean) * rstd * g4[c][j].w + b4[c][j].w;
+          xr[c][4 * j] = kok[c] ? o0 : 0.f; xr[c][4 * j + 1] = kok[c] ? o1 : 0.f;
+          xr[c][4 * j + 2] = kok[c] ? o2 : 0.f; xr[c][4 * j + 3] = kok[c] ? o3 : 0.f;
+        }
     }
   }
-  __syncthreads();
 
-  // ---- this lane's slice of x, kept in registers across row groups
-  float xr[KCH][VEC];
-#pragma unroll
-  for (int c = 0; c < KCH; ++c) {
-    const int k = (c * 64 + lane) * VEC;
-#pragma unroll
-    for (int j = 0; j < VEC; j += 4) {
-      const float4 t = (k < K) ? *reinterpret_cast<const float4*>(xs + k + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-      xr[c][j] = t.x; xr[c][j + 1] = t.y; xr[c][j + 2] = t.z; xr[c][j + 3] = t.w;
-    }
-  }
-
+  // ---- (D) dot products, wave reduction, epilogue -------------------------------------------
   for (;;) {
     float acc[RPW];
 #pragma unroll
@@ -158,18 +199,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) s = fmaf(wf[j], xr[c][j], s);
       }
-      acc[r] = wave_sum(s);
+      acc[r] = s;
     }
-    // epilogue: lane r finishes row r
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) acc[r] = wave_sum_dpp(acc[r]);
     float mine = 0.f;
 #pragma unroll
     for (int r = 0; r < RPW; ++r) mine = (lane == r) ? acc[r] : mine;
     const int row = g * RPW + lane;
     if (lane < RPW && row < N) {
-      float v = mine + ((a.bias != nullptr) ? a.bias[row] : 0.f);
+      const float v = mine + e_bias;
       switch (a.epi) {
         case EPI_RELU: a.y[row] = fmaxf(v, 0.f); break;
-        case EPI_RESID: a.y[row] = a.y[row] + v; break;
+        case EPI_RESID: a.y[row] = e_res + v; break;
         case EPI_LOGITS:  // a finished decode keeps replaying the step: leave its last logits row intact
           if (!st_done) a.y[(size_t)(st_trace ? st_pass : 0) * N + row] = v;
           break;
@@ -188,101 +230,107 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     }
     g += nwaves;
     if (g * RPW >= N) break;
+    {
+      const int rc = min(g * RPW + min(lane, RPW - 1), N - 1);
+      if (has_bias) e_bias = a.bias[rc];
+      if (has_res) e_res = a.y[rc];
+    }
     issue(g);
   }
 }
 
 // ---- single-query attention over the KV cache, split over keys (flash-decoding) -----------
-// grid = nhead * nsplit.  Cache layout (nhead, ctx_max, HD): one head's keys are contiguous, so a
-// wave-load covers 64/LPK whole keys with 16-byte lanes.  Each group of LPK lanes keeps an
-// online-softmax state; groups are merged with wave shuffles, waves through LDS.
+// grid = nhead * ATT_NSPLIT workgroups of 256.  Cache layout (nhead, ctx_max, 64): one head's keys
+// are contiguous, a wave-load covers 64/LPK whole keys with 16-byte lanes.  Two passes over
+// registers: scores of all of this workgroup's keys (K and V loads issued together up front),
+// one workgroup max, then p = exp(s - max) and P.V with plain sums — no per-key rescale.
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ q, const T* __restrict__ kc,
                                                           const T* __restrict__ vc, float* __restrict__ part,
-                                                          const ArState* __restrict__ st, int ctx_max, int nsplit,
-                                                          float scale) {
+                                                          const ArState* __restrict__ st, int ctx_max, float scale) {
   constexpr int VEC = Vec16<T>::N;
-  constexpr int LPK = HD / VEC;   // lanes per key
-  constexpr int KPW = 64 / LPK;   // keys per wave-iteration
-  constexpr int UNR = 4;
-  __shared__ float sm_m[4], sm_l[4], sm_o[4][HD];
-  const int h = blockIdx.x / nsplit, s = blockIdx.x - h * nsplit;
+  constexpr int LPK = HD / VEC;        // lanes per key: 8 (bf16) / 16 (fp32)
+  constexpr int KPW = 64 / LPK;        // keys per wave-load
+  constexpr int KPB = 4 * KPW;         // keys per workgroup round
+  constexpr int UNR = 6;               // rounds held in registers: UNR * KPB keys per outer pass
+  __shared__ float sm_red[4];
+  __shared__ __attribute__((aligned(16))) float sm_o[4 * KPW][HD + 1];
+  __shared__ float sm_l[4 * KPW];
+  const int h = blockIdx.x / ATT_NSPLIT, s = blockIdx.x - h * ATT_NSPLIT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPK, grp = lane / LPK;
   const int ctx = st->row + 1;
-  const int chunk = (ctx + nsplit - 1) / nsplit;
+  const int chunk = (ctx + ATT_NSPLIT - 1) / ATT_NSPLIT;
   const int j0 = s * chunk, j1 = min(ctx, j0 + chunk);
 
   float qv[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) qv[i] = q[h * HD + sub * VEC + i];
-
+  for (int i = 0; i < VEC; i += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(q + h * HD + sub * VEC + i);
+    qv[i] = t.x; qv[i + 1] = t.y; qv[i + 2] = t.z; qv[i + 3] = t.w;
+  }
   const T* kb = kc + (size_t)h * ctx_max * HD + sub * VEC;
   const T* vb = vc + (size_t)h * ctx_max * HD + sub * VEC;
-  float m = -INFINITY, l = 0.f, acc[VEC];
+
+  float M = -INFINITY, L = 0.f, acc[VEC];  // carried across outer passes (one pass while ctx <= NSPLIT*UNR*KPB)
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
 
-  for (int jb = j0 + wave * KPW + grp; jb < j1; jb += 4 * KPW * UNR) {
+  for (int base = j0; base < j1; base += UNR * KPB) {
     uint4 kr[UNR], vr[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const int j = jb + u * 4 * KPW;
+      const int j = base + u * KPB + wave * KPW + grp;
       if (j < j1) { kr[u] = ld16(kb + (size_t)j * HD); vr[u] = ld16(vb + (size_t)j * HD); }
       else { kr[u] = make_uint4(0u, 0u, 0u, 0u); vr[u] = kr[u]; }
     }
+    float sc[UNR], mloc = -INFINITY;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const int j = jb + u * 4 * KPW;
-      float kf[VEC], vf[VEC];
+      const int j = base + u * KPB + wave * KPW + grp;
+      float kf[VEC];
       unpack<T>(kr[u], kf);
-      unpack<T>(vr[u], vf);
       float dot = 0.f;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) dot = fmaf(kf[i], qv[i], dot);
+      dot = (LPK == 8) ? group8_sum_dpp(dot) : group16_sum_dpp(dot);
+      sc[u] = (j < j1) ? dot * scale : -INFINITY;
+      mloc = fmaxf(mloc, sc[u]);
+    }
+    // workgroup max of this pass (uniform trip count: base/j1 are workgroup-uniform)
+    mloc = wave_max_dpp(mloc);
+    __syncthreads();
+    if (lane == 0) sm_red[wave] = mloc;
+    __syncthreads();
+    const float mb = fmaxf(fmaxf(sm_red[0], sm_red[1]), fmaxf(sm_red[2], sm_red[3]));
+    const float Mn = fmaxf(M, mb);
+    const float corr = (M == -INFINITY) ? 0.f : expf(M - Mn);  // 0 on the first pass
+    L *= corr;
 #pragma unroll
-      for (int o = 1; o < LPK; o <<= 1) dot += __shfl_xor(dot, o, WAVE);
-      if (j < j1) {  // uniform within the LPK-lane group
-        const float sc = dot * scale;
-        const float mn = fmaxf(m, sc);
-        const float corr = expf(m - mn);  // m = -inf -> 0
-        const float p = expf(sc - mn);
-        l = l * corr + p;
+    for (int i = 0; i < VEC; ++i) acc[i] *= corr;
+    M = Mn;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = acc[i] * corr + p * vf[i];
-        m = mn;
-      }
+    for (int u = 0; u < UNR; ++u) {
+      float vf[VEC];
+      unpack<T>(vr[u], vf);
+      const float p = (sc[u] == -INFINITY) ? 0.f : expf(sc[u] - M);
+      L += p;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, vf[i], acc[i]);
     }
   }
-  // merge the KPW groups of this wave
+  // sum the 4*KPW key groups: LDS transpose, thread c sums channel c
+  const int gi = wave * KPW + grp;
 #pragma unroll
-  for (int o = LPK; o < 64; o <<= 1) {
-    const float m2 = __shfl_xor(m, o, WAVE), l2 = __shfl_xor(l, o, WAVE);
-    const float mn = fmaxf(m, m2);
-    const float c1 = (m == -INFINITY) ? 0.f : expf(m - mn);
-    const float c2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
-    l = l * c1 + l2 * c2;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] = acc[i] * c1 + __shfl_xor(acc[i], o, WAVE) * c2;
-    m = mn;
-  }
-  if (grp == 0) {
-    if (sub == 0) { sm_m[wave] = m; sm_l[wave] = l; }
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) sm_o[wave][sub * VEC + i] = acc[i];
-  }
+  for (int i = 0; i < VEC; ++i) sm_o[gi][sub * VEC + i] = acc[i];
+  if (sub == 0) sm_l[gi] = L;
   __syncthreads();
   if (tid < HD) {
-    float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
-    float L = 0.f, o = 0.f;
+    float o = 0.f, l = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float f = (sm_m[w] == -INFINITY) ? 0.f : expf(sm_m[w] - M);
-      L += sm_l[w] * f;
-      o += sm_o[w][tid] * f;
-    }
-    float* p = part + (size_t)blockIdx.x * (4 + HD);
-    if (tid == 0) { p[0] = M; p[1] = L; }
+    for (int gidx = 0; gidx < 4 * KPW; ++gidx) { o += sm_o[gidx][tid]; l += sm_l[gidx]; }
+    float* p = part + (size_t)blockIdx.x * ATT_PSTRIDE;
+    if (tid == 0) { p[0] = M; p[1] = l; }
     p[4 + tid] = o;
   }
 }
@@ -316,105 +364,129 @@ __device__ __forceinline__ float device_exp1(unsigned long long seed, int pass, 
   return -logf(u);
 }
 
-// One workgroup of 1024 threads; thread t owns logits t and t+1024.
-__global__ __launch_bounds__(1024) void sample_embed_kernel(const SampleArgs a) {
-  __shared__ float redv[16];
-  __shared__ int redi[16];
-  __shared__ int cnt[2][16];
-  __shared__ int s_tok, s_go;
+// ONE wave: lane l owns logits l, l+64, ..., l+64*(NV-1) in registers.  Everything the stop rule
+// depends on is a wave-level DPP reduction or a ballot — no LDS, no barrier on the token's critical path.
+template <int NV>
+__global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
   ArState* st = a.st;
   if (st->done) return;  // uniform
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lane = threadIdx.x;
   const int V = a.V;
   const int pass = st->pass;
   const float* lg = a.logits + (st->trace_logits ? (size_t)pass * V : 0);
-  const bool has0 = t < V, has1 = (t + 1024) < V;
-  float v0 = has0 ? lg[t] : -INFINITY;
-  float v1 = has1 ? lg[t + 1024] : -INFINITY;
+  const float* nz = st->exp_noise;
+  if (nz != nullptr) nz += (size_t)min((long long)pass, st->noise_rows - 1) * V;
+  float v[NV], qn[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = j * 64 + lane;
+    v[j] = (i < V) ? lg[i] : -INFINITY;
+    qn[j] = (nz != nullptr && i < V) ? nz[i] : 1.f;
+  }
+  const float temp = st->temperature;
+  const int top_k = st->top_k;
+  const unsigned long long seed = st->seed;
+  const int n_gen = st->n_gen, bos = st->bos, S = st->S, max_new = st->max_new, n_forced = st->n_forced;
+  const long long* forced = st->forced;
+  const int row = st->row + 1;  // KV row of the new token
+  const float alpha = a.alpha[0];
+  if (nz == nullptr) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) qn[j] = device_exp1(seed, pass, j * 64 + lane);
+  }
 
   // argmax of the raw logits (valle.py:1045); first index on ties
-  ValIdx c0{v0, t}, c1{v1, t + 1024};
-  const ValIdx am = block_argmax<16>(better(c0, c1), redv, redi);
+  ValIdx am{v[0], lane};
+#pragma unroll
+  for (int j = 1; j < NV; ++j) am = better(am, ValIdx{v[j], j * 64 + lane});
+  am = wave_argmax_dpp(am);
 
-  const float temp = st->temperature;
-  if (temp != 1.0f) { v0 = v0 / temp; v1 = v1 / temp; }  // valle.py:1296-1297
+  if (temp != 1.0f) {  // valle.py:1296-1297
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = v[j] / temp;
+  }
 
-  // top-k: keep v >= (k-th largest value), ties kept (valle.py:1254-1260).  The threshold is
-  // found by a 32-step bitwise select on order-preserving integer keys: exact, k-independent.
-  bool keep0 = has0, keep1 = has1;
-  int k = st->top_k;
-  if (k > 0 && k < V) {
-    const uint32_t key0 = has0 ? order_key(v0) : 0u, key1 = has1 ? order_key(v1) : 0u;
-    uint32_t T = 0u;
+  // top-k: keep v >= (k-th largest), ties kept (valle.py:1254-1260).  Bitwise select of the k-th largest
+  // order-preserving key; counts are ballots (scalar), so every branch below is wave-uniform.
+  uint32_t T = 0u;
+  if (top_k > 0 && top_k < V) {
+    uint32_t key[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) key[j] = (j * 64 + lane < V) ? order_key(v[j]) : 0u;
     for (int b = 31; b >= 0; --b) {
       const uint32_t cand = T | (1u << b);
-      const int c = __popcll(__ballot(key0 >= cand)) + __popcll(__ballot(key1 >= cand));
-      if (lane == 0) cnt[b & 1][wave] = c;
-      __syncthreads();
-      int tot = 0;
+      int c = 0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) tot += cnt[b & 1][i];
-      if (tot >= k) T = cand;
+      for (int j = 0; j < NV; ++j) c += __popcll(__ballot(key[j] >= cand));
+      if (c >= top_k) {
+        T = cand;
+        if (c == top_k) {  // the kept set is exactly {key >= cand}: its minimum is the k-th largest
+          uint32_t mn = 0xffffffffu;
+#pragma unroll
+          for (int j = 0; j < NV; ++j) mn = (key[j] >= cand) ? min(mn, key[j]) : mn;
+          T = wave_umin_dpp(mn);
+          break;
+        }
+      }
     }
-    keep0 = has0 && key0 >= T;
-    keep1 = has1 && key1 >= T;
   }
+  bool keep[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) keep[j] = (j * 64 + lane < V) && (T == 0u || order_key(v[j]) >= T);
 
   // softmax over the kept entries (F.softmax, valle.py:1301)
-  const float mx = block_max<16>(fmaxf(keep0 ? v0 : -INFINITY, keep1 ? v1 : -INFINITY), redv);
-  const float e0 = keep0 ? expf(v0 - mx) : 0.f, e1 = keep1 ? expf(v1 - mx) : 0.f;
-  const float Z = block_sum<16>(e0 + e1, redv);
-  const float p0 = e0 / Z, p1 = e1 / Z;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) mx = fmaxf(mx, keep[j] ? v[j] : -INFINITY);
+  mx = wave_max_dpp(mx);
+  float e[NV], zs = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { e[j] = keep[j] ? expf(v[j] - mx) : 0.f; zs += e[j]; }
+  const float Z = wave_sum_dpp(zs);
 
   // multinomial(p, 1) == argmax(p / q), q ~ Exp(1)
-  float q0, q1;
-  if (a.st->exp_noise != nullptr) {
-    const float* nz = a.st->exp_noise + (size_t)min((long long)pass, a.st->noise_rows - 1) * V;
-    q0 = has0 ? nz[t] : 1.f;
-    q1 = has1 ? nz[t + 1024] : 1.f;
-  } else {
-    q0 = device_exp1(st->seed, pass, t);
-    q1 = device_exp1(st->seed, pass, t + 1024);
+  ValIdx sm{-1.f, 0x7fffffff};
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = j * 64 + lane;
+    if (i < V) sm = better(sm, ValIdx{(e[j] / Z) / qn[j], i});
   }
-  ValIdx r0{has0 ? p0 / q0 : -1.f, t}, r1{has1 ? p1 / q1 : -1.f, t + 1024};
-  const ValIdx smp = block_argmax<16>(better(r0, r1), redv, redi);
+  sm = wave_argmax_dpp(sm);
 
-  // stop rule + append (valle.py:1044-1057); thread 0 owns the state
-  if (t == 0) {
-    a.sampled[pass] = smp.i;
-    a.argmaxes[pass] = am.i;
-    int tok = smp.i, go = 0, reason = 0;
-    const int n_gen = st->n_gen;
-    const bool forcing = st->forced != nullptr;
-    if (forcing) {
-      if (pass >= st->n_forced) reason = 4; else tok = (int)st->forced[pass];
-    } else if (am.i == NUM_AUDIO_TOKENS) reason = 1;
-    else if (smp.i == NUM_AUDIO_TOKENS) reason = 2;
-    else if (st->bos + n_gen > 16 * st->S) reason = 3;
-    else if (st->max_new >= 0 && n_gen >= st->max_new) reason = 4;
-    if (reason == 0) {
-      a.tokens[n_gen] = tok;
-      st->n_gen = n_gen + 1;
-      // after this append the next pass can only stop (valle.py:1047): skip computing it
-      if (!forcing && st->bos + n_gen + 1 > 16 * st->S) reason = 3;
-      else if (!forcing && st->max_new >= 0 && n_gen + 1 >= st->max_new) reason = 4;
-      if (reason == 0) go = 1;
-    }
-    if (reason != 0) { st->done = 1; st->stop_reason = reason; }
-    s_tok = tok;
-    s_go = go;
+  // stop rule + append (valle.py:1044-1057); every lane evaluates the same scalars
+  int tok = sm.i, reason = 0;
+  bool append = false, go = false;
+  if (forced != nullptr) {
+    if (pass >= n_forced) reason = 4;
+    else { tok = (int)forced[pass]; append = true; go = true; }
+  } else if (am.i == NUM_AUDIO_TOKENS) reason = 1;
+  else if (sm.i == NUM_AUDIO_TOKENS) reason = 2;
+  else if (bos + n_gen > 16 * S) reason = 3;
+  else if (max_new >= 0 && n_gen >= max_new) reason = 4;
+  else {
+    append = true; go = true;
+    // after this append the next pass could only stop (valle.py:1047): do not compute it
+    if (bos + n_gen + 1 > 16 * S) { reason = 3; go = false; }
+    else if (max_new >= 0 && n_gen + 1 >= max_new) { reason = 4; go = false; }
   }
-  __syncthreads();
-  if (!s_go) return;
+  if (lane == 0) {
+    a.sampled[pass] = sm.i;
+    a.argmaxes[pass] = am.i;
+    if (append) { a.tokens[n_gen] = tok; st->n_gen = n_gen + 1; }
+    if (reason != 0) { st->done = 1; st->stop_reason = reason; }
+    if (go) { st->row = row; st->pass = pass + 1; }
+  }
+  if (!go) return;
   // x = E[tok] * 1.0 + alpha * pe[audio position] (valle.py:1013-1015; embedding.py:93-97)
-  const int tok = s_tok;
-  const int row = st->row + 1;                 // KV row of the new token
-  const int apos = row - st->S;                // position inside the audio sub-sequence
-  const float alpha = a.alpha[0];
-  for (int c = t; c < a.d; c += 1024)
-    a.x[c] = __fadd_rn(a.emb[(size_t)tok * a.d + c], __fmul_rn(alpha, a.pe[(size_t)apos * a.d + c]));
-  __syncthreads();
-  if (t == 0) { st->row = row; st->pass = pass + 1; }
+  const int apos = row - S;
+  for (int c = lane * 4; c < a.d; c += 256) {
+    const float4 ev = *reinterpret_cast<const float4*>(a.emb + (size_t)tok * a.d + c);
+    const float4 pv = *reinterpret_cast<const float4*>(a.pe + (size_t)apos * a.d + c);
+    float4 o;
+    o.x = __fadd_rn(ev.x, __fmul_rn(alpha, pv.x)); o.y = __fadd_rn(ev.y, __fmul_rn(alpha, pv.y));
+    o.z = __fadd_rn(ev.z, __fmul_rn(alpha, pv.z)); o.w = __fadd_rn(ev.w, __fmul_rn(alpha, pv.w));
+    *reinterpret_cast<float4*>(a.x + c) = o;
+  }
 }
 
 }  // namespace vx

@@ -39,6 +39,60 @@ template <typename T> __device__ __forceinline__ void unpack(const uint4& r, flo
 }
 template <typename T> __device__ __forceinline__ uint4 ld16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
 
+// ---- DPP reductions (VALU cross-lane, no LDS round trip; ds_bpermute-based __shfl costs ~10x) ----
+// dpp_ctrl: 0xB1 quad_perm[1,0,3,2], 0x4E quad_perm[2,3,0,1], 0x124/0x128 row_ror:4/8,
+// 0x141 row_half_mirror, 0x140 row_mirror, 0x142 row_bcast:15 (rows 1,3), 0x143 row_bcast:31 (rows 2,3).
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp_f(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ int dpp_i(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ float lane63(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// every lane returns the sum over the 64 lanes (fixed tree order -> deterministic)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_f<0xB1>(0.f, v);
+  v += dpp_f<0x4E>(0.f, v);
+  v += dpp_f<0x124>(0.f, v);
+  v += dpp_f<0x128>(0.f, v);
+  v += dpp_f<0x142, 0xA>(0.f, v);
+  v += dpp_f<0x143, 0xC>(0.f, v);
+  return lane63(v);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v, v));
+  v = fmaxf(v, dpp_f<0x4E>(v, v));
+  v = fmaxf(v, dpp_f<0x124>(v, v));
+  v = fmaxf(v, dpp_f<0x128>(v, v));
+  v = fmaxf(v, dpp_f<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_f<0x143, 0xC>(v, v));
+  return lane63(v);
+}
+__device__ __forceinline__ uint32_t wave_umin_dpp(uint32_t v) {
+  v = min(v, (uint32_t)dpp_i<0xB1>((int)v, (int)v));
+  v = min(v, (uint32_t)dpp_i<0x4E>((int)v, (int)v));
+  v = min(v, (uint32_t)dpp_i<0x124>((int)v, (int)v));
+  v = min(v, (uint32_t)dpp_i<0x128>((int)v, (int)v));
+  v = min(v, (uint32_t)dpp_i<0x142, 0xA>((int)v, (int)v));
+  v = min(v, (uint32_t)dpp_i<0x143, 0xC>((int)v, (int)v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// sum over aligned groups of 8 / 16 lanes; every lane of the group gets the group sum
+__device__ __forceinline__ float group8_sum_dpp(float v) {
+  v += dpp_f<0xB1>(0.f, v);
+  v += dpp_f<0x4E>(0.f, v);
+  v += dpp_f<0x141>(0.f, v);
+  return v;
+}
+__device__ __forceinline__ float group16_sum_dpp(float v) {
+  v = group8_sum_dpp(v);
+  v += dpp_f<0x140>(0.f, v);
+  return v;
+}
+
 // ---- reductions ------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -80,6 +134,24 @@ template <int NW> __device__ __forceinline__ float block_max(float v, float* red
 struct ValIdx { float v; int i; };
 __device__ __forceinline__ ValIdx better(ValIdx a, ValIdx b) {
   return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ ValIdx argmax_step_dpp(ValIdx a) {
+  ValIdx b;
+  b.v = dpp_f<CTRL, ROW_MASK>(a.v, a.v);  // masked rows read themselves: better(a, a) == a
+  b.i = dpp_i<CTRL, ROW_MASK>(a.i, a.i);
+  return better(a, b);
+}
+__device__ __forceinline__ ValIdx wave_argmax_dpp(ValIdx a) {
+  a = argmax_step_dpp<0xB1>(a);
+  a = argmax_step_dpp<0x4E>(a);
+  a = argmax_step_dpp<0x124>(a);
+  a = argmax_step_dpp<0x128>(a);
+  a = argmax_step_dpp<0x142, 0xA>(a);
+  a = argmax_step_dpp<0x143, 0xC>(a);
+  ValIdx r;
+  r.v = lane63(a.v);
+  r.i = __builtin_amdgcn_readlane(a.i, 63);
+  return r;
 }
 __device__ __forceinline__ ValIdx wave_argmax(ValIdx a) {
 #pragma unroll

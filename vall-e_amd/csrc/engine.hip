@@ -59,7 +59,6 @@ struct LayerW {
   const float *n1_g, *n1_b, *n2_g, *n2_b;
 };
 
-constexpr int NSPLIT = 8;
 constexpr int POLL_CHUNK = 32;
 
 struct vx_engine {
@@ -227,7 +226,7 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   // AR
   VXC(dalloc_t(e, &e->ar_x, d));
   VXC(dalloc_t(e, &e->ar_q, d));
-  VXC(dalloc_t(e, &e->ar_part, (size_t)H * NSPLIT * (4 + hd)));
+  VXC(dalloc_t(e, &e->ar_part, (size_t)H * ATT_NSPLIT * ATT_PSTRIDE));
   VXC(dalloc_t(e, &e->ar_f, 4 * (size_t)d));
   const size_t nlog = (c.flags & VX_FLAG_TRACE_LOGITS) ? (size_t)c.max_audio + 2 : 1;
   VXC(dalloc_t(e, &e->ar_logits, nlog * AR_VOCAB));
@@ -379,28 +378,36 @@ extern "C" int vx_finalize_weights(vx_engine* e) {
 }
 
 // ------------------------------------------------------------------------------ launch helpers
-template <typename WT, int KCH, int RPW>
+template <typename WT, int KCH, int RPW, int PRO>
 static void launch_gemv_inst(const GemvArgs& a, int grid, hipStream_t s) {
-  const size_t lds = (size_t)(((a.K + 3) & ~3) + 8) * sizeof(float);
-  gemv_kernel<WT, KCH, RPW><<<grid, 256, lds, s>>>(a);
+  gemv_kernel<WT, KCH, RPW, PRO><<<grid, 256, 0, s>>>(a);
 }
 
-template <typename WT> static int launch_gemv_t(const GemvArgs& a, int num_cu, hipStream_t s) {
+// Chooses the instance: KCH = 16-byte chunks per lane per row, RPW = rows per wave so that one
+// wave-iteration covers N over 4*grid waves, with at most 16 weight registers-quads in flight.
+template <typename WT, int PRO> static int launch_gemv_p(const GemvArgs& a, int num_cu, hipStream_t s) {
   constexpr int VEC = Vec16<WT>::N;
   if (a.K % VEC || a.K > 4096 || a.K % 4) return fail(VX_ERR_UNSUPPORTED, "gemv: K=%d unsupported", a.K);
   const int need_kch = (a.K + 64 * VEC - 1) / (64 * VEC);
   int kch = 1;
   while (kch < need_kch) kch <<= 1;
-  if (kch > 16) return fail(VX_ERR_UNSUPPORTED, "gemv: K=%d too large", a.K);
+  if (kch > 16 || (PRO != PRO_COPY && (kch > 4 || a.K > 1024))) return fail(VX_ERR_UNSUPPORTED, "gemv: K=%d too large for prologue %d", a.K, PRO);
   int grid = num_cu;
   if ((a.N + 3) / 4 < grid) grid = (a.N + 3) / 4;
   const int need_rpw = (a.N + grid * 4 - 1) / (grid * 4);
   int rpw = need_rpw >= 3 ? 4 : need_rpw;
   while (rpw * kch > 16 && rpw > 1) rpw >>= 1;
-#define GV(KC, RP) if (kch == KC && rpw == RP) { launch_gemv_inst<WT, KC, RP>(a, grid, s); return VX_OK; }
-  GV(1, 1) GV(1, 2) GV(1, 4) GV(2, 1) GV(2, 2) GV(2, 4) GV(4, 1) GV(4, 2) GV(4, 4) GV(8, 1) GV(8, 2) GV(16, 1)
+#define GV(KC, RP) if (kch == KC && rpw == RP) { launch_gemv_inst<WT, KC, RP, PRO>(a, grid, s); return VX_OK; }
+  GV(1, 1) GV(1, 2) GV(1, 4) GV(2, 1) GV(2, 2) GV(2, 4) GV(4, 1) GV(4, 2) GV(4, 4)
+  if constexpr (PRO == PRO_COPY) { GV(8, 1) GV(8, 2) GV(16, 1) }
 #undef GV
   return fail(VX_ERR_UNSUPPORTED, "gemv: no instance for kch=%d rpw=%d", kch, rpw);
+}
+
+template <typename WT> static int launch_gemv_t(const GemvArgs& a, int num_cu, hipStream_t s) {
+  if (a.pro == PRO_LN) return launch_gemv_p<WT, PRO_LN>(a, num_cu, s);
+  if (a.pro == PRO_ATTN) return launch_gemv_p<WT, PRO_ATTN>(a, num_cu, s);
+  return launch_gemv_p<WT, PRO_COPY>(a, num_cu, s);
 }
 
 static int launch_gemv(bool bf, const GemvArgs& a, int num_cu, hipStream_t s) {
@@ -566,7 +573,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
   sa.emb = W<float>(e, "ar_audio_embedding.word_embeddings.weight");
   sa.alpha = W<float>(e, "ar_audio_position.alpha");
   sa.pe = e->pe_ar; sa.x = e->ar_x; sa.d = d;
-  sample_embed_kernel<<<1, 1024, 0, s>>>(sa);
+  sample_embed_kernel<17><<<1, 64, 0, s>>>(sa);
   const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd * e->esz;
   const float scale = 1.0f / sqrtf((float)hd);
   for (int li = 0; li < c.num_layers; ++li) {
@@ -574,16 +581,16 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     char* kc = (char*)e->kv + (size_t)li * kv_layer;
     char* vc = kc + kv_layer / 2;
     GemvArgs a{};
-    a.st = e->d_st; a.d = d; a.hd = hd; a.ctx_max = e->ctx_max; a.nhead = H; a.nsplit = NSPLIT;
+    a.st = e->d_st; a.d = d; a.hd = hd; a.ctx_max = e->ctx_max; a.nhead = H;
     // qkv = in_proj(LN1(x)); k,v appended to the cache (transformer.py:297-301)
     a.W = l.in_w; a.bias = l.in_b; a.x = e->ar_x; a.gamma = l.n1_g; a.beta = l.n1_b;
     a.N = 3 * d; a.K = d; a.pro = PRO_LN; a.epi = EPI_QKV; a.q = e->ar_q; a.kcache = kc; a.vcache = vc;
     VXC(launch_gemv(e->bf16, a, e->num_cu, s));
-    if (e->bf16) attn_decode_kernel<bf16, 64><<<H * NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, NSPLIT, scale);
-    else attn_decode_kernel<float, 64><<<H * NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, NSPLIT, scale);
+    if (e->bf16) attn_decode_kernel<bf16, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale);
+    else attn_decode_kernel<float, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale);
     // x += out_proj(attn)
     GemvArgs o{};
-    o.st = e->d_st; o.hd = hd; o.nhead = H; o.nsplit = NSPLIT;
+    o.st = e->d_st; o.hd = hd; o.nhead = H;
     o.W = l.out_w; o.bias = l.out_b; o.part = e->ar_part; o.y = e->ar_x; o.N = d; o.K = d; o.pro = PRO_ATTN; o.epi = EPI_RESID;
     VXC(launch_gemv(e->bf16, o, e->num_cu, s));
     // f = relu(linear1(LN2(x)))
@@ -884,7 +891,8 @@ extern "C" int vx_op_sample(const float* logits, int32_t V, int32_t top_k, float
   sa.logits = logits; sa.V = V; sa.st = dst;
   sa.tokens = scratch; sa.sampled = scratch + 4; sa.argmaxes = scratch + 8;
   sa.emb = fz; sa.alpha = fz; sa.pe = fz; sa.x = fz + 2048; sa.d = 0;
-  sample_embed_kernel<<<1, 1024, 0, s>>>(sa);
+  if (V <= 17 * 64) sample_embed_kernel<17><<<1, 64, 0, s>>>(sa);
+  else sample_embed_kernel<32><<<1, 64, 0, s>>>(sa);
   HIPC(hipGetLastError());
   int host[16];
   HIPC(hipMemcpyAsync(host, scratch, sizeof host, hipMemcpyDeviceToHost, s));
@@ -892,5 +900,46 @@ extern "C" int vx_op_sample(const float* logits, int32_t V, int32_t top_k, float
   out[0] = host[4];
   out[1] = host[8];
   (void)hipFree(dst); (void)hipFree(scratch); (void)hipFree(fz);
+  return VX_OK;
+}
+
+// ------------------------------------------------------------------------------ measurement aid
+__global__ void noop_kernel(float* p) {
+  if (p != nullptr && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) p[0] = 0.f;
+}
+
+// Launch floor of this box: time of a dependent chain of n trivial kernels (grid x block), replayed
+// `iters` times as a hipGraph and launched eagerly.  out[0] = us per kernel (graph), out[1] = eager.
+extern "C" int vx_debug_launch_floor(int32_t n_kernels, int32_t grid, int32_t block, int32_t iters, double* out) {
+  if (!out || n_kernels <= 0 || iters <= 0) return fail(VX_ERR_ARG, "bad argument");
+  hipStream_t s;
+  HIPC(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  hipEvent_t e0, e1;
+  HIPC(hipEventCreate(&e0));
+  HIPC(hipEventCreate(&e1));
+  hipGraph_t g;
+  hipGraphExec_t ge;
+  HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < n_kernels; ++i) noop_kernel<<<grid, block, 0, s>>>(nullptr);
+  HIPC(hipStreamEndCapture(s, &g));
+  HIPC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  for (int i = 0; i < 3; ++i) HIPC(hipGraphLaunch(ge, s));
+  HIPC(hipStreamSynchronize(s));
+  float ms = 0.f;
+  HIPC(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) HIPC(hipGraphLaunch(ge, s));
+  HIPC(hipEventRecord(e1, s));
+  HIPC(hipStreamSynchronize(s));
+  HIPC(hipEventElapsedTime(&ms, e0, e1));
+  out[0] = (double)ms * 1e3 / ((double)iters * n_kernels);
+  HIPC(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i)
+    for (int k = 0; k < n_kernels; ++k) noop_kernel<<<grid, block, 0, s>>>(nullptr);
+  HIPC(hipEventRecord(e1, s));
+  HIPC(hipStreamSynchronize(s));
+  HIPC(hipEventElapsedTime(&ms, e0, e1));
+  out[1] = (double)ms * 1e3 / ((double)iters * n_kernels);
+  (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
   return VX_OK;
 }

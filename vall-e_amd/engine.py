@@ -61,6 +61,7 @@ _SIGS = {
     "vx_op_attention": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
     "vx_op_sample": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "vx_op_convert_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "vx_debug_launch_floor": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
 }
 
 
@@ -263,3 +264,10 @@ def op_sample(logits, top_k, temperature, exp_noise):
     _check(lib.vx_op_sample(_ptr(logits), logits.numel(), int(top_k), float(temperature), _ptr(exp_noise), out,
                             current_stream_ptr(logits.device)))
     return out[0], out[1]
+
+
+def launch_floor(n_kernels=62, grid=256, block=256, iters=200):
+    lib = load_library()
+    out = (C.c_double * 2)()
+    _check(lib.vx_debug_launch_floor(n_kernels, grid, block, iters, out))
+    return dict(graph_us_per_kernel=out[0], eager_us_per_kernel=out[1])
