@@ -91,7 +91,8 @@ struct vx_engine {
   // row buffers
   int n_max = 0;
   float* X = nullptr;
-  void *Hn = nullptr, *QKV = nullptr, *ATT = nullptr, *FF = nullptr;
+  void *Hn = nullptr, *QKV = nullptr, *ATT = nullptr, *FF = nullptr, *VT = nullptr;
+  int vt_ld = 0;
   float *yemb = nullptr, *nar_logits = nullptr, *ada = nullptr;
   long long *ids_text = nullptr, *ids_audio = nullptr, *ids_prompts = nullptr, *ids_samples = nullptr, *d_codes = nullptr;
   // graph
@@ -242,6 +243,9 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   VXC(dalloc(e, &e->Hn, n * dmax * e->esz));
   VXC(dalloc(e, &e->QKV, n * 3 * dmax * e->esz));
   VXC(dalloc(e, &e->ATT, n * dmax * e->esz));
+  e->vt_ld = ((e->n_max + 63) / 64) * 64 + 64;  // key-padded row length of V^T (16-byte aligned tiles)
+  VXC(dalloc(e, &e->VT, (size_t)dmax * e->vt_ld * 2));
+  HIPC(hipMemset(e->VT, 0, (size_t)dmax * e->vt_ld * 2));  // padding keys must stay finite (they meet P = 0)
   VXC(dalloc(e, &e->FF, n * 4 * dmax * e->esz));
   VXC(dalloc_t(e, &e->yemb, (size_t)c.max_audio * dn));
   VXC(dalloc_t(e, &e->nar_logits, (size_t)c.max_audio * 1024));
@@ -416,9 +420,9 @@ static int launch_gemv(bool bf, const GemvArgs& a, int num_cu, hipStream_t s) {
 
 template <typename T>
 static int gemm_rows_t(bool mfma, const T* A, const T* Wt, const float* bias, void* C, int M, int N, int K, int epi,
-                       bool out_f32, hipStream_t s) {
+                       bool out_f32, hipStream_t s, void* vt = nullptr, int vt_n0 = 0, int vt_ld = 0) {
   if constexpr (std::is_same<T, bf16>::value) {
-    if (mfma) return mfma_gemm_dispatch(A, Wt, bias, C, M, N, K, epi, out_f32, s);
+    if (mfma) return mfma_gemm_dispatch(A, Wt, bias, C, M, N, K, epi, out_f32, s, (bf16*)vt, vt_n0, vt_ld);
   }
   dim3 grid((N + 63) / 64, (M + 63) / 64);
   if (epi == GE_RESID) gemm_simple_kernel<T, float, GE_RESID><<<grid, 256, 0, s>>>(A, Wt, bias, (float*)C, M, N, K);
@@ -433,8 +437,10 @@ static int gemm_rows_t(bool mfma, const T* A, const T* Wt, const float* bias, vo
 static bool use_mfma(const vx_engine* e) { return e->bf16 && !(e->cfg.flags & VX_FLAG_SIMPLE_ROWS); }
 
 static int gemm_rows(vx_engine* e, const void* A, const void* Wt, const float* bias, void* C, int M, int N, int K,
-                     int epi, bool out_f32) {
-  if (e->bf16) return gemm_rows_t<bf16>(use_mfma(e), (const bf16*)A, (const bf16*)Wt, bias, C, M, N, K, epi, out_f32, e->es);
+                     int epi, bool out_f32, bool emit_vt = false) {
+  if (e->bf16)
+    return gemm_rows_t<bf16>(use_mfma(e), (const bf16*)A, (const bf16*)Wt, bias, C, M, N, K, epi, out_f32, e->es,
+                             emit_vt ? e->VT : nullptr, 2 * (N / 3), e->vt_ld);
   return gemm_rows_t<float>(false, (const float*)A, (const float*)Wt, bias, C, M, N, K, epi, out_f32, e->es);
 }
 
@@ -447,7 +453,7 @@ static int ln_rows(vx_engine* e, const float* x, const float* g, const float* b,
 
 static int attn_rows(vx_engine* e, const void* qkv, void* out, int M, int d, int H, int text_len) {
   const float scale = 1.0f / sqrtf(64.0f);
-  if (use_mfma(e)) return mfma_attn_dispatch((const bf16*)qkv, (bf16*)out, M, d, H, text_len, scale, e->es);
+  if (use_mfma(e)) return mfma_attn_dispatch((const bf16*)qkv, (const bf16*)e->VT, e->vt_ld, (bf16*)out, M, d, H, text_len, e->es);
   dim3 grid((M + 63) / 64, H);
   if (e->bf16) attn_rows_simple_kernel<bf16, 64><<<grid, 256, 0, e->es>>>((const bf16*)qkv, (bf16*)out, M, d, text_len, scale);
   else attn_rows_simple_kernel<float, 64><<<grid, 256, 0, e->es>>>((const float*)qkv, (float*)out, M, d, text_len, scale);
@@ -468,7 +474,7 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
       aw2 = ada_vec(e, ada_stage, 2 * (int)li + 1); ab2 = aw2 + d;
     }
     VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d));
-    VXC(gemm_rows(e, e->Hn, l.in_w, l.in_b, e->QKV, M, 3 * d, d, GE_BIAS, false));
+    VXC(gemm_rows(e, e->Hn, l.in_w, l.in_b, e->QKV, M, 3 * d, d, GE_BIAS, false, use_mfma(e)));
     if (fill_cache) {
       char* kc = (char*)e->kv + li * kv_layer;
       char* vc = kc + kv_layer / 2;
@@ -860,7 +866,15 @@ extern "C" int vx_op_attention(int32_t prec, int32_t mfma, const void* qkv, void
   const float scale = 1.0f / sqrtf((float)hd);
   dim3 grid((rows + 63) / 64, nhead);
   if (prec == VX_PREC_BF16) {
-    if (mfma) VXC(mfma_attn_dispatch((const bf16*)qkv, (bf16*)out, rows, d, nhead, text_len, scale, s));
+    if (mfma) {
+      const int vt_ld = ((rows + 63) / 64) * 64 + 64;
+      bf16* vt = nullptr;
+      HIPC(hipMalloc((void**)&vt, (size_t)d * vt_ld * 2));
+      vt_from_qkv_kernel<<<dim3((vt_ld + 255) / 256, d), 256, 0, s>>>((const bf16*)qkv, vt, rows, d, vt_ld);
+      VXC(mfma_attn_dispatch((const bf16*)qkv, vt, vt_ld, (bf16*)out, rows, d, nhead, text_len, s));
+      HIPC(hipStreamSynchronize(s));
+      HIPC(hipFree(vt));
+    }
     else attn_rows_simple_kernel<bf16, 64><<<grid, 256, 0, s>>>((const bf16*)qkv, (bf16*)out, rows, d, text_len, scale);
   } else {
     if (mfma) return fail(VX_ERR_UNSUPPORTED, "MFMA attention is bf16 only");

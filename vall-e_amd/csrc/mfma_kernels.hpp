@@ -20,7 +20,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                         const float* __restrict__ bias, void* __restrict__ Cv, int M,
-                                                        int N, int K) {
+                                                        int N, int K, bf16* __restrict__ vt, int vt_n0, int vt_ld) {
   constexpr int BM = 128, BN = 128, BK = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // layout: [buf][A|W][128 rows * 128 B]
@@ -106,6 +106,10 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
             *c = (EPI == GE_RESID) ? (*c + x) : x;
           } else {
             reinterpret_cast<bf16*>(Cv)[(size_t)m * N + n] = (bf16)x;
+            // V columns of the packed QKV projection are also written transposed, (channel, row): the
+            // accumulator has its column on the lane, so this is contiguous in m for free and gives the
+            // flash-attention kernel its key-contiguous V operand without an in-kernel transpose.
+            if (vt != nullptr && n >= vt_n0) vt[(size_t)(n - vt_n0) * vt_ld + m] = (bf16)x;
           }
         }
       }
@@ -114,7 +118,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
 }
 
 static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* bias, void* C, int M, int N, int K,
-                                     int epi, bool out_f32, hipStream_t s) {
+                                     int epi, bool out_f32, hipStream_t s, bf16* vt = nullptr, int vt_n0 = 0,
+                                     int vt_ld = 0) {
   if (K % 64 != 0 || N % 8 != 0) {
     // shapes outside the tiling: scalar-FMA fallback
     dim3 g((N + 63) / 64, (M + 63) / 64);
@@ -135,7 +140,7 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
       (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       attr_done = true;                                                                                      \
     }                                                                                                        \
-    mfma_gemm_kernel<E, F><<<grid, 256, lds, s>>>(A, W, bias, C, M, N, K);                                   \
+    mfma_gemm_kernel<E, F><<<grid, 256, lds, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld);                                   \
   } while (0)
   if (epi == GE_RESID) MG(GE_RESID, true);
   else if (epi == GE_PLAIN) MG(GE_PLAIN, true);
@@ -147,11 +152,181 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
   return 0;
 }
 
-// MFMA flash attention is not built yet: bf16 rows use the tiled scalar-FMA kernel.
-static inline int mfma_attn_dispatch(const bf16* qkv, bf16* out, int M, int d, int H, int text_len, float scale,
-                                     hipStream_t s) {
-  dim3 grid((M + 63) / 64, H);
-  attn_rows_simple_kernel<bf16, 64><<<grid, 256, 0, s>>>(qkv, out, M, d, text_len, scale);
+// ---- flash attention over rows (NAR stages: no mask; AR prefill: the reference's prefix mask) ----
+// One wave = 32 queries, workgroup = NW waves sharing 64-key K / V^T tiles in LDS (double-buffered).
+// Orientation (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand"):
+//   S^T[key][query] = K . Q^T     A = K rows from LDS, B = Q rows (registers, pre-scaled by 1/8, exact)
+//   O^T[dim][query] = V^T . P^T   A = V^T rows from LDS, B = the S^T accumulator itself, cast to bf16
+// so the query index stays on the LANE in both products: the online-softmax statistics and the
+// rescale of O are per-lane scalars, the key reduction is over the 16 accumulator registers plus one
+// half-wave exchange, and P never leaves registers.
+__device__ __forceinline__ float xor32_f(float v) {
+  // v_permlane32_swap: lanes 32-63 of the 1st operand swap with lanes 0-31 of the 2nd
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mfma_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
+                                                            bf16* __restrict__ out, int M, int vt_ld, int d,
+                                                            int text_len) {
+  constexpr int HD = 64, NT = NW * 64;
+  constexpr int CPT = 512 / NT;  // 16-byte chunks per thread per operand tile (64 rows x 8 chunks)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][64 * 128];  // [buf][K | V^T][row * 128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const int ld3 = 3 * d;
+  const int qrow = q0 + r;
+  const bool qvalid = qrow < M;
+
+  // Q fragments for the 4 k-steps of 16 dims, scaled by 1/sqrt(64) = 2^-3 (exact in bf16)
+  bf16x8_t qf[4];
+  {
+    const bf16* qp = qkv + (size_t)min(qrow, M - 1) * ld3 + head * HD + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16)((float)qf[ks][j] * 0.125f);
+    }
+  }
+  // keys visible to this lane's query: [0, limit)
+  const int limit = !qvalid ? 0 : (text_len < 0 ? M : (qrow < text_len ? text_len : qrow + 1));
+  int blk_limit = M;  // highest key any query of the workgroup may see
+  if (text_len >= 0) {
+    const int last = min(M, (int)(blockIdx.x + 1) * 32 * NW) - 1;
+    blk_limit = last < text_len ? text_len : last + 1;
+  }
+  const int ntiles = (blk_limit + 63) / 64;
+
+  uint4 rk[CPT], rv[CPT];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int q = tid + i * NT, row = q >> 3, c = q & 7;
+      rk[i] = ld16(qkv + (size_t)min(kt + row, M - 1) * ld3 + d + head * HD + c * 8);  // key row, 8 dims
+      rv[i] = ld16(vt + (size_t)(head * HD + row) * vt_ld + kt + c * 8);              // channel row, 8 keys
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int q = tid + i * NT, row = q >> 3, c = q & 7;
+      const int off = row * 128 + ((c ^ (row & 7)) << 4);
+      *reinterpret_cast<uint4*>(&lds[buf][0][off]) = rk[i];
+      *reinterpret_cast<uint4*>(&lds[buf][1][off]) = rv[i];
+    }
+  };
+
+  f32x16_t accO[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) accO[t][v] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // l_run: this half-wave's share of the row sum
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int it = 0; it < ntiles; ++it) {
+    const int cur = it & 1, kt = it * 64;
+    if (it + 1 < ntiles) gload(kt + 64);
+    const unsigned char* kb = &lds[cur][0][0];
+    const unsigned char* vb = &lds[cur][1][0];
+    // S^T for the two 32-key sub-tiles
+    f32x16_t accS[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) accS[sub][v] = 0.f;
+      const int krow = sub * 32 + r;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + krow * 128 + (((ks * 2 + hh) ^ (krow & 7)) << 4));
+        accS[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], accS[sub], 0, 0, 0);
+      }
+    }
+    // mask + running max (register v of half hh holds key (v&3) + 8(v>>2) + 4hh of the sub-tile)
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int kg = kt + sub * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
+        const float sv = (kg < limit) ? accS[sub][v] : -INFINITY;
+        accS[sub][v] = sv;
+        mloc = fmaxf(mloc, sv);
+      }
+    mloc = fmaxf(mloc, xor32_f(mloc));
+    const float m_new = fmaxf(m_run, mloc);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: exp(-inf - 0) = 0
+    const float corr = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);
+    m_run = m_new;
+    l_run *= corr;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) accO[t][v] *= corr;
+    // P^T = exp(S^T - m), cast to bf16 in accumulator order = B fragments of the next product
+    bf16x8_t pf[2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const float p = __expf(accS[sub][v] - m_use);
+        l_run += p;
+        pf[sub][v >> 3][v & 7] = (bf16)p;
+      }
+    // O^T += V^T . P^T : element j of half hh is key 16s + 8(j>>2) + 4hh + (j&3) of the sub-tile
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int c0 = sub * 4 + s2 * 2;  // 16-byte chunk of keys [sub*32 + 16*s2, +8); the second half is chunk c0+1
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int vrow = t * 32 + r;
+          const unsigned char* rowp = vb + vrow * 128 + 8 * hh;
+          union { bf16x8_t v8; uint2 u[2]; } vf;
+          vf.u[0] = *reinterpret_cast<const uint2*>(rowp + ((c0 ^ (vrow & 7)) << 4));
+          vf.u[1] = *reinterpret_cast<const uint2*>(rowp + (((c0 + 1) ^ (vrow & 7)) << 4));
+          accO[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v8, pf[sub][s2], accO[t], 0, 0, 0);
+        }
+      }
+    if (it + 1 < ntiles) lstore(cur ^ 1);
+    __syncthreads();
+  }
+  const float l_tot = l_run + xor32_f(l_run);
+  if (qvalid) {
+    const float inv = 1.0f / l_tot;
+    bf16* op = out + (size_t)qrow * d + head * HD;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {  // registers 4g4..4g4+3 = dims t*32 + 8*g4 + 4*hh + 0..3
+        union { bf16 b[4]; uint2 u; } pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk.b[j] = (bf16)(accO[t][4 * g4 + j] * inv);
+        *reinterpret_cast<uint2*>(op + t * 32 + 8 * g4 + 4 * hh) = pk.u;
+      }
+  }
+}
+
+// (channel, row) transpose of the V third of a packed qkv buffer (only for the stand-alone op test;
+// in the engine the QKV GEMM epilogue writes V^T itself)
+__global__ __launch_bounds__(256) void vt_from_qkv_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ vt, int M, int d,
+                                                          int vt_ld) {
+  const int m = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  if (m < vt_ld) vt[(size_t)c * vt_ld + m] = (m < M) ? qkv[(size_t)m * 3 * d + 2 * d + c] : (bf16)0.f;
+}
+
+static inline int mfma_attn_dispatch(const bf16* qkv, const bf16* vt, int vt_ld, bf16* out, int M, int d, int H,
+                                     int text_len, hipStream_t s) {
+  constexpr int NW = 2;
+  dim3 grid((M + 32 * NW - 1) / (32 * NW), H);
+  mfma_attn_kernel<NW><<<grid, NW * 64, 0, s>>>(qkv, vt, out, M, vt_ld, d, text_len);
   return 0;
 }
 
