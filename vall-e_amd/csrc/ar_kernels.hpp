@@ -355,13 +355,15 @@ __device__ __forceinline__ uint32_t order_key(float v) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Exp(1) draw of the on-device sampler: counter-based 32-bit hash of (seed, pass, index).  64-bit
+// multiplies are quarter-rate VALU sequences; this mix uses two 32-bit ones.
 __device__ __forceinline__ float device_exp1(unsigned long long seed, int pass, int i) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)pass * 2048ull + (unsigned long long)i + 1ull);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  const float u = ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
-  return -logf(u);
+  uint32_t x = (uint32_t)(seed ^ (seed >> 32)) + 0x9E3779B9u * (uint32_t)(pass + 1) + 0x632BE5ABu * (uint32_t)(i + 1);
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  const float u = ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+  return -__logf(u);
 }
 
 // ONE wave: lane l owns logits l, l+64, ..., l+64*(NV-1) in registers.  Everything the stop rule
@@ -390,10 +392,6 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
   const long long* forced = st->forced;
   const int row = st->row + 1;  // KV row of the new token
   const float alpha = a.alpha[0];
-  if (nz == nullptr) {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) qn[j] = device_exp1(seed, pass, j * 64 + lane);
-  }
 
   // argmax of the raw logits (valle.py:1045); first index on ties
   ValIdx am{v[0], lane};
@@ -434,22 +432,35 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
 #pragma unroll
   for (int j = 0; j < NV; ++j) keep[j] = (j * 64 + lane < V) && (T == 0u || order_key(v[j]) >= T);
 
-  // softmax over the kept entries (F.softmax, valle.py:1301)
+  // softmax over the kept entries (F.softmax, valle.py:1301).  Registers in which no lane kept anything
+  // (most of them under top-k) skip exp / RNG / the two IEEE divisions wave-uniformly.
+  bool any[NV];
   float mx = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < NV; ++j) mx = fmaxf(mx, keep[j] ? v[j] : -INFINITY);
+  for (int j = 0; j < NV; ++j) {
+    any[j] = __ballot(keep[j]) != 0ull;
+    mx = fmaxf(mx, keep[j] ? v[j] : -INFINITY);
+  }
   mx = wave_max_dpp(mx);
   float e[NV], zs = 0.f;
 #pragma unroll
-  for (int j = 0; j < NV; ++j) { e[j] = keep[j] ? expf(v[j] - mx) : 0.f; zs += e[j]; }
+  for (int j = 0; j < NV; ++j) {
+    e[j] = 0.f;
+    if (any[j]) { e[j] = keep[j] ? expf(v[j] - mx) : 0.f; zs += e[j]; }
+  }
   const float Z = wave_sum_dpp(zs);
 
-  // multinomial(p, 1) == argmax(p / q), q ~ Exp(1)
+  // multinomial(p, 1) == argmax(p / q), q ~ Exp(1); entries with p = 0 can only win if nothing is kept
   ValIdx sm{-1.f, 0x7fffffff};
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int i = j * 64 + lane;
-    if (i < V) sm = better(sm, ValIdx{(e[j] / Z) / qn[j], i});
+    if (any[j]) {
+      const float q = (nz != nullptr) ? qn[j] : device_exp1(seed, pass, i);
+      if (i < V) sm = better(sm, ValIdx{(e[j] / Z) / q, i});
+    } else if (i < V) {
+      sm = better(sm, ValIdx{0.f, i});
+    }
   }
   sm = wave_argmax_dpp(sm);
 
