@@ -34,6 +34,17 @@ def ar_bytes_per_token(d: int, L: int, ctx: float, bpe: int = 2) -> float:
     return weights + 2 * L * d * bpe * (ctx + 1)
 
 
+def measured_traffic(ctx_mean: float):
+    """HBM bytes per AR step from the committed PMC profile (profiles/r01_pmc_ar_step.json: FETCH_SIZE x2 as the
+    microarch guide prescribes for gfx950, split into the ctx-independent GEMV part and the per-cached-row
+    attention part so that it can be quoted at this run's mean context).  None if the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_ar_step.json")
+    if not os.path.isfile(path):
+        return None
+    p = json.load(open(path))
+    return int(p["gemv_bytes_per_step_corrected"] + p["attn_bytes_per_ctx_row_corrected"] * ctx_mean)
+
+
 def cpu_baseline(sd, cfg, x, x_lens, y, n_tokens: int):
     """The reference algorithm (no KV cache, fp32, oracle/valle_oracle.inference_faithful — a checked
     port, kind="port") on a bounded sample of the same workload, timed on this box's host cores."""
@@ -62,6 +73,7 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=16)
+    ap.add_argument("--no-graph", action="store_true", help="launch the AR step kernel by kernel (rocprofv3 --pmc cannot follow hipGraph replays)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,7 +100,8 @@ def main():
 
     cfg = ModelConfig(decoder_dim=1024, nhead=16, num_decoder_layers=12, prefix_mode=1)
     sd = synthetic_state_dict(cfg, seed=0)
-    model = VALLE(1024, 16, 12, prefix_mode=1, precision=args.precision, max_text=64, max_audio=1024, print_eos=False)
+    model = VALLE(1024, 16, 12, prefix_mode=1, precision=args.precision, max_text=64, max_audio=1024, print_eos=False,
+                  no_graph=args.no_graph)
     model.load_state_dict(sd)
     model.to(dev).eval()
     eng = model.engine()
@@ -154,7 +167,8 @@ def main():
             "nar_7stage_ms": round(tm["nar_ms"], 3),
             "roofline": {"bound": "hbm", "kernel": "AR decode step (hipGraph of 62 kernels = 1 token)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": measured_traffic(ctx_mean) if args.precision == "bf16" else None,
                          "bytes_per_launch": int(ar_bytes_per_token(1024, 12, ctx_mean, bpe))},
         }
         if world == 1 and not args.no_cpu_baseline:

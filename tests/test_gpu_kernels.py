@@ -111,7 +111,8 @@ def test_attention_rows(eng, N, H, text_len):
         assert (outb - refb).abs().max() <= 2e-2  # bf16 output rounding (|out| <~ 3) (+ bf16 P in the MFMA path)
 
 
-@pytest.mark.parametrize("top_k,temp", [(-100, 1.0), (1, 1.0), (10, 1.0), (50, 0.7), (1025, 1.3), (2000, 1.0), (3, 2.0)])
+@pytest.mark.parametrize("top_k,temp", [(-100, 1.0), (1, 1.0), (10, 1.0), (50, 0.7), (64, 1.0), (65, 0.9), (100, 1.0),
+                                        (1024, 1.0), (1025, 1.3), (2000, 1.0), (3, 2.0)])
 def test_sampling_matches_oracle_bit_exact(eng, top_k, temp):
     """Index selection (argmax, top-k set, sampled token) must equal the oracle's exactly."""
     from oracle import valle_oracle as vo

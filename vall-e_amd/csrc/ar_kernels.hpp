@@ -19,6 +19,7 @@ namespace vx {
 enum GemvPro { PRO_COPY = 0, PRO_LN = 1, PRO_ATTN = 2 };
 enum GemvEpi { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU = 2, EPI_RESID = 3, EPI_QKV = 4, EPI_LOGITS = 5 };
 
+constexpr int LOGITS_CUR = 1088;     // floats reserved for the newest logits row at the buffer head; trace rows follow
 constexpr int ATT_NSPLIT = 8;        // key splits per head in the decode attention
 constexpr int ATT_PSTRIDE = 4 + 64;  // floats per partial: {m, l, -, -, o[64]}
 
@@ -213,7 +214,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         case EPI_RELU: a.y[row] = fmaxf(v, 0.f); break;
         case EPI_RESID: a.y[row] = e_res + v; break;
         case EPI_LOGITS:  // a finished decode keeps replaying the step: leave its last logits row intact
-          if (!st_done) a.y[(size_t)(st_trace ? st_pass : 0) * N + row] = v;
+          if (!st_done) {
+            a.y[row] = v;  // fixed address: the sampling kernel's loads do not wait for the step counter
+            if (st_trace) a.y[LOGITS_CUR + (size_t)st_pass * N + row] = v;
+          }
           break;
         case EPI_QKV: {
           const int sec = row / a.d, i = row - sec * a.d;
@@ -366,6 +370,20 @@ __device__ __forceinline__ float device_exp1(unsigned long long seed, int pass, 
   return -__logf(u);
 }
 
+// k-th largest of one key per lane (needs >= k non-zero keys): bitwise select, ballot counts.
+__device__ __forceinline__ uint32_t kth_largest_1reg(uint32_t x, int k) {
+  uint32_t T = 0u;
+  for (int b = 31; b >= 0; --b) {
+    const uint32_t cand = T | (1u << b);
+    const int c = __popcll(__ballot(x >= cand));
+    if (c >= k) {
+      T = cand;
+      if (c == k) return wave_umin_dpp(x >= cand ? x : 0xffffffffu);
+    }
+  }
+  return T;
+}
+
 // ONE wave: lane l owns logits l, l+64, ..., l+64*(NV-1) in registers.  Everything the stop rule
 // depends on is a wave-level DPP reduction or a ballot — no LDS, no barrier on the token's critical path.
 template <int NV>
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
   const int lane = threadIdx.x;
   const int V = a.V;
   const int pass = st->pass;
-  const float* lg = a.logits + (st->trace_logits ? (size_t)pass * V : 0);
+  const float* lg = a.logits;  // newest row, fixed address
   const float* nz = st->exp_noise;
   if (nz != nullptr) nz += (size_t)min((long long)pass, st->noise_rows - 1) * V;
   float v[NV], qn[NV];
@@ -404,26 +422,59 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
     for (int j = 0; j < NV; ++j) v[j] = v[j] / temp;
   }
 
-  // top-k: keep v >= (k-th largest), ties kept (valle.py:1254-1260).  Bitwise select of the k-th largest
-  // order-preserving key; counts are ballots (scalar), so every branch below is wave-uniform.
+  // top-k: keep v >= (k-th largest), ties kept (valle.py:1254-1260).  The threshold is the k-th largest
+  // order-preserving key, found exactly by bitwise select with ballot counts (all branches wave-uniform).
+  // For k <= 64 the search is first narrowed: the k-th largest of the 64 per-lane maxima is a lower bound L
+  // of the answer, so only keys >= L (usually k..k+3 of them) can matter; they are compacted into one
+  // register through LDS and selected there (1 compare per round instead of 17).
   uint32_t T = 0u;
   if (top_k > 0 && top_k < V) {
+    __shared__ uint32_t cand_lds[64];
     uint32_t key[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) key[j] = (j * 64 + lane < V) ? order_key(v[j]) : 0u;
-    for (int b = 31; b >= 0; --b) {
-      const uint32_t cand = T | (1u << b);
-      int c = 0;
+    bool found = false;
+    if (top_k <= 64) {
+      uint32_t lm = key[0];
 #pragma unroll
-      for (int j = 0; j < NV; ++j) c += __popcll(__ballot(key[j] >= cand));
-      if (c >= top_k) {
-        T = cand;
-        if (c == top_k) {  // the kept set is exactly {key >= cand}: its minimum is the k-th largest
-          uint32_t mn = 0xffffffffu;
+      for (int j = 1; j < NV; ++j) lm = max(lm, key[j]);
+      const uint32_t L = kth_largest_1reg(lm, top_k);
+      int cL = 0;
 #pragma unroll
-          for (int j = 0; j < NV; ++j) mn = (key[j] >= cand) ? min(mn, key[j]) : mn;
-          T = wave_umin_dpp(mn);
-          break;
+      for (int j = 0; j < NV; ++j) cL += __popcll(__ballot(key[j] >= L));
+      if (cL == top_k) {
+        T = L;
+        found = true;
+      } else if (cL <= 64) {
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const unsigned long long mk = __ballot(key[j] >= L);
+          const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+          if (key[j] >= L) cand_lds[pos] = key[j];
+          base += __popcll(mk);
+        }
+        __syncthreads();  // one wave: orders the LDS writes before the reads
+        const uint32_t c = (lane < cL) ? cand_lds[lane] : 0u;
+        T = kth_largest_1reg(c, top_k);
+        found = true;
+      }
+    }
+    if (!found) {
+      for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = T | (1u << b);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) c += __popcll(__ballot(key[j] >= cand));
+        if (c >= top_k) {
+          T = cand;
+          if (c == top_k) {  // the kept set is exactly {key >= cand}: its minimum is the k-th largest
+            uint32_t mn = 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) mn = (key[j] >= cand) ? min(mn, key[j]) : mn;
+            T = wave_umin_dpp(mn);
+            break;
+          }
         }
       }
     }

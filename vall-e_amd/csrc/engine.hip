@@ -230,7 +230,7 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   VXC(dalloc_t(e, &e->ar_part, (size_t)H * ATT_NSPLIT * ATT_PSTRIDE));
   VXC(dalloc_t(e, &e->ar_f, 4 * (size_t)d));
   const size_t nlog = (c.flags & VX_FLAG_TRACE_LOGITS) ? (size_t)c.max_audio + 2 : 1;
-  VXC(dalloc_t(e, &e->ar_logits, nlog * AR_VOCAB));
+  VXC(dalloc_t(e, &e->ar_logits, LOGITS_CUR + nlog * AR_VOCAB));
   VXC(dalloc(e, &e->kv, (size_t)c.num_layers * 2 * H * e->ctx_max * hd * e->esz));
   VXC(dalloc_t(e, &e->d_st, 1));
   HIPC(hipHostMalloc((void**)&e->h_st, 3 * sizeof(ArState)));
@@ -803,7 +803,10 @@ extern "C" int vx_read_buffer(vx_engine* e, const char* name, void* dst, int64_t
   const char* src = nullptr;
   int64_t size = 0;
   const bool trace = e->cfg.flags & VX_FLAG_TRACE_LOGITS;
-  if (n == "ar_logits") { src = (const char*)e->ar_logits; size = (int64_t)(trace ? e->n_pass : 1) * AR_VOCAB * 4; }
+  if (n == "ar_logits") {
+    src = (const char*)(trace ? e->ar_logits + LOGITS_CUR : e->ar_logits);
+    size = (int64_t)(trace ? e->n_pass : 1) * AR_VOCAB * 4;
+  }
   else if (n == "ar_sampled") { src = (const char*)e->d_sampled; size = (int64_t)e->n_pass * 4; }
   else if (n == "ar_argmax") { src = (const char*)e->d_argmax; size = (int64_t)e->n_pass * 4; }
   else if (n == "nar_logits") { src = (const char*)e->nar_logits; size = (int64_t)e->last_T * 1024 * 4; }

@@ -4,6 +4,8 @@
 // lane (r = l&31, h = l>>5) holds 8 consecutive k (one 16-byte LDS read) of row r of A and of
 // row r of W (cdna_hip_programming.md §3 "A/B operand lane maps").
 #pragma once
+#include <cstdlib>
+
 #include "common.hpp"
 #include "rows_kernels.hpp"
 
@@ -117,10 +119,135 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
   }
 }
 
+// ---- wave-tile GEMM: every wave owns one 64x64 output tile and stages its own A / W tiles through a
+// wave-private, double-buffered LDS region, so the K loop has NO workgroup barrier: the four waves of a
+// CU drift freely and hide each other's global-load latency (at M ~ 1k rows there is about one
+// workgroup per CU, so nothing else would).  SPLITK = 1: the 4 waves of a workgroup take 4 neighbouring
+// N tiles of one M tile (the A rows hit L1).  SPLITK = 4: the 4 waves take the 4 quarters of K of ONE
+// tile and are summed through LDS in a fixed order (deterministic) — used when N/64 x M/64 tiles alone
+// would leave the chip idle (the N = 1024 out-projection / FFN2 / predict GEMMs).
+// Block ids are laid out so that all M tiles of one N group share blockIdx % 8, i.e. an XCD and its L2
+// (speed only; dispatch placement is not a contract).
+template <int EPI, bool OUT_F32, int SPLITK>
+__global__ __launch_bounds__(256) void wgemm_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                                    const float* __restrict__ bias, void* __restrict__ Cv, int M, int N,
+                                                    int K, bf16* __restrict__ vt, int vt_n0, int vt_ld, int ngroups,
+                                                    int ngroups_pad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [wave][buf][A 8 KB | W 8 KB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int ng = blockIdx.x % ngroups_pad, mt = blockIdx.x / ngroups_pad;
+  if (ng >= ngroups) return;
+  const int m0 = mt * 64;
+  const int n0 = (SPLITK == 1) ? (ng * 4 + wave) * 64 : ng * 64;
+  const int kbeg = (SPLITK == 1) ? 0 : wave * (K / SPLITK);
+  const int nk = (K / SPLITK) / 64;
+  unsigned char* my = lds + wave * 32768;
+  const bool active = n0 < N;  // SPLITK == 1: the last group may be partial
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  if (active) {
+    uint4 ra[8], rw[8];
+    auto gload = [&](int k0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = lane + i * 64, row = q >> 3, c = q & 7;
+        ra[i] = ld16(A + (size_t)min(m0 + row, M - 1) * K + k0 + c * 8);
+        rw[i] = ld16(W + (size_t)min(n0 + row, N - 1) * K + k0 + c * 8);
+      }
+    };
+    auto lstore = [&](int buf) {
+      unsigned char* ba = my + buf * 16384;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = lane + i * 64, row = q >> 3, c = q & 7;
+        const int off = row * 128 + ((c ^ (row & 7)) << 4);
+        *reinterpret_cast<uint4*>(ba + off) = ra[i];
+        *reinterpret_cast<uint4*>(ba + 8192 + off) = rw[i];
+      }
+    };
+    gload(kbeg);
+    lstore(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) gload(kbeg + (kt + 1) * 64);
+      const unsigned char* ba = my + cur * 16384;
+      const unsigned char* bw = ba + 8192;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8_t fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = i * 32 + r;
+          const int off = row * 128 + (((ks * 2 + h) ^ (row & 7)) << 4);
+          fa[i] = *reinterpret_cast<const bf16x8_t*>(ba + off);
+          fb[i] = *reinterpret_cast<const bf16x8_t*>(bw + off);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      if (kt + 1 < nk) lstore(cur ^ 1);
+    }
+  }
+
+  auto emit = [&](int m, int n, float x) {
+    if (m < M && n < N) {
+      if (EPI != GE_PLAIN) x += bias[n];
+      if (EPI == GE_RELU) x = fmaxf(x, 0.f);
+      if (OUT_F32) {
+        float* c = reinterpret_cast<float*>(Cv) + (size_t)m * N + n;
+        *c = (EPI == GE_RESID) ? (*c + x) : x;
+      } else {
+        reinterpret_cast<bf16*>(Cv)[(size_t)m * N + n] = (bf16)x;
+        if (vt != nullptr && n >= vt_n0) vt[(size_t)(n - vt_n0) * vt_ld + m] = (bf16)x;
+      }
+    }
+  };
+
+  if (SPLITK == 1) {
+    if (!active) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          emit(m0 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h, n0 + j * 32 + r, acc[i][j][v]);
+  } else {
+    // fixed-order sum of the 4 K-quarters through LDS: slab w = wave w's 64x64 fp32 tile (16 KB)
+    __syncthreads();  // every wave is done reading its staging buffers
+    float* slab = reinterpret_cast<float*>(lds) + wave * 4096;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          slab[(i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h) * 64 + j * 32 + r] = acc[i][j][v];
+    __syncthreads();
+    const float* all = reinterpret_cast<const float*>(lds);
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {  // wave w finishes rows [16w, 16w+16), lane = column
+      const int ml = wave * 16 + rr;
+      const float x = ((all[ml * 64 + lane] + all[4096 + ml * 64 + lane]) + all[8192 + ml * 64 + lane]) + all[12288 + ml * 64 + lane];
+      emit(m0 + ml, n0 + lane, x);
+    }
+  }
+}
+
 static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* bias, void* C, int M, int N, int K,
                                      int epi, bool out_f32, hipStream_t s, bf16* vt = nullptr, int vt_n0 = 0,
                                      int vt_ld = 0) {
-  if (K % 64 != 0 || N % 8 != 0) {
+  if (K % 64 != 0 || N % 64 != 0) {
     // shapes outside the tiling: scalar-FMA fallback
     dim3 g((N + 63) / 64, (M + 63) / 64);
     if (epi == GE_RESID) gemm_simple_kernel<bf16, float, GE_RESID><<<g, 256, 0, s>>>(A, W, bias, (float*)C, M, N, K);
@@ -131,24 +258,58 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
     else gemm_simple_kernel<bf16, bf16, GE_RELU><<<g, 256, 0, s>>>(A, W, bias, (bf16*)C, M, N, K);
     return 0;
   }
-  dim3 grid((N + 127) / 128, (M + 127) / 128);
-  const size_t lds = 65536;
-#define MG(E, F)                                                                                             \
-  do {                                                                                                       \
-    static bool attr_done = false;                                                                           \
-    if (!attr_done) {                                                                                        \
-      (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr_done = true;                                                                                      \
-    }                                                                                                        \
-    mfma_gemm_kernel<E, F><<<grid, 256, lds, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld);                                   \
+  static const int alg = [] { const char* v = getenv("VX_GEMM_ALG"); return v ? atoi(v) : 0; }();
+  if (alg == 1) {  // A/B: the 128x128 shared-tile kernel
+    dim3 grid((N + 127) / 128, (M + 127) / 128);
+#define MG(E, F)                                                                                                        \
+  do {                                                                                                                  \
+    static bool attr_done = false;                                                                                      \
+    if (!attr_done) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
+      attr_done = true;                                                                                                 \
+    }                                                                                                                   \
+    mfma_gemm_kernel<E, F><<<grid, 256, 65536, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld);                          \
   } while (0)
-  if (epi == GE_RESID) MG(GE_RESID, true);
-  else if (epi == GE_PLAIN) MG(GE_PLAIN, true);
-  else if (epi == GE_BIAS && out_f32) MG(GE_BIAS, true);
-  else if (epi == GE_RELU && out_f32) MG(GE_RELU, true);
-  else if (epi == GE_BIAS) MG(GE_BIAS, false);
-  else MG(GE_RELU, false);
+    if (epi == GE_RESID) MG(GE_RESID, true);
+    else if (epi == GE_PLAIN) MG(GE_PLAIN, true);
+    else if (epi == GE_BIAS && out_f32) MG(GE_BIAS, true);
+    else if (epi == GE_RELU && out_f32) MG(GE_RELU, true);
+    else if (epi == GE_BIAS) MG(GE_BIAS, false);
+    else MG(GE_RELU, false);
 #undef MG
+    return 0;
+  }
+  const int mtiles = (M + 63) / 64;
+  const size_t lds = 131072;
+#define WG(E, F, S)                                                                                                     \
+  do {                                                                                                                  \
+    static bool attr_done = false;                                                                                      \
+    if (!attr_done) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)wgemm_kernel<E, F, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_done = true;                                                                                                 \
+    }                                                                                                                   \
+    const int ngr = (S == 1) ? (N + 255) / 256 : N / 64;                                                                \
+    const int ngp = (ngr + 7) / 8 * 8;                                                                                  \
+    wgemm_kernel<E, F, S><<<mtiles * ngp, 256, lds, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ngr, ngp);             \
+  } while (0)
+  // split K inside the workgroup when the tile grid alone cannot fill 4 waves on each of the 256 CUs
+  const bool split = (K % 256 == 0) && ((long long)mtiles * (N / 64) < 512);
+  if (split) {
+    if (epi == GE_RESID) WG(GE_RESID, true, 4);
+    else if (epi == GE_PLAIN) WG(GE_PLAIN, true, 4);
+    else if (epi == GE_BIAS && out_f32) WG(GE_BIAS, true, 4);
+    else if (epi == GE_RELU && out_f32) WG(GE_RELU, true, 4);
+    else if (epi == GE_BIAS) WG(GE_BIAS, false, 4);
+    else WG(GE_RELU, false, 4);
+  } else {
+    if (epi == GE_RESID) WG(GE_RESID, true, 1);
+    else if (epi == GE_PLAIN) WG(GE_PLAIN, true, 1);
+    else if (epi == GE_BIAS && out_f32) WG(GE_BIAS, true, 1);
+    else if (epi == GE_RELU && out_f32) WG(GE_RELU, true, 1);
+    else if (epi == GE_BIAS) WG(GE_BIAS, false, 1);
+    else WG(GE_RELU, false, 1);
+  }
+#undef WG
   return 0;
 }
 
