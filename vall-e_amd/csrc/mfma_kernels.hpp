@@ -5,6 +5,7 @@
 // row r of W (cdna_hip_programming.md §3 "A/B operand lane maps").
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 #include "rows_kernels.hpp"
@@ -39,36 +40,34 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-  // staging: 1024 16-byte chunks per operand tile, 4 per thread
-  uint4 ra[4], rw[4];
-  auto gload = [&](int k0) {
+  // staging: 1024 16-byte chunks per operand tile, 4 per thread; THREE register sets so that three
+  // K tiles of global loads are in flight while one is being multiplied (at M ~ 1k rows there is
+  // about one workgroup per CU, so nothing else hides the load latency: one tile ahead ran at
+  // ~20 GB/s per CU).  Tile t always lives in set t % 3; vmcnt retires in order, so the wait in
+  // front of each LDS store only covers that tile's loads.
+  uint4 ra[3][4], rw[3][4];
+  auto gload = [&](auto SET, int k0) {
+    constexpr int S = decltype(SET)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = tid + i * 256, row = q >> 3, c = q & 7;
-      const int gm = m0 + row, gn = n0 + row;
-      ra[i] = (gm < M) ? ld16(A + (size_t)gm * K + k0 + c * 8) : make_uint4(0u, 0u, 0u, 0u);
-      rw[i] = (gn < N) ? ld16(W + (size_t)gn * K + k0 + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+      ra[S][i] = ld16(A + (size_t)min(m0 + row, M - 1) * K + k0 + c * 8);
+      rw[S][i] = ld16(W + (size_t)min(n0 + row, N - 1) * K + k0 + c * 8);
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](auto SET, int buf) {
+    constexpr int S = decltype(SET)::value;
     unsigned char* ba = lds + buf * 32768;
     unsigned char* bw = ba + 16384;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = tid + i * 256, row = q >> 3, c = q & 7;
       const int off = row * 128 + ((c ^ (row & 7)) << 4);
-      *reinterpret_cast<uint4*>(ba + off) = ra[i];
-      *reinterpret_cast<uint4*>(bw + off) = rw[i];
+      *reinterpret_cast<uint4*>(ba + off) = ra[S][i];
+      *reinterpret_cast<uint4*>(bw + off) = rw[S][i];
     }
   };
-
-  const int nk = K / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+  auto compute = [&](int cur) {
     const unsigned char* ba = lds + cur * 32768;
     const unsigned char* bw = ba + 16384;
 #pragma unroll
@@ -86,9 +85,34 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) lstore(cur ^ 1);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  const int nk = K / BK;
+  // one pipeline step for tile t (set S = t % 3, next tile's set N = (t + 1) % 3)
+  auto step = [&](auto SET, auto NEXT, int t) {
+    // set S was freed by the LDS store at the end of step t-1.  UNCONDITIONAL (k clamped): a load under a
+    // branch makes hipcc's vmcnt bookkeeping conservative and the wait before the LDS store below
+    // degenerates to vmcnt(0), i.e. a one-tile pipeline.
+    gload(SET, min((t + 3) * BK, K - BK));
+    compute(t & 1);
+    if (t + 1 < nk) lstore(NEXT, (t + 1) & 1);
     __syncthreads();
+  };
+  gload(I0{}, 0);
+  gload(I1{}, min(BK, K - BK));
+  gload(I2{}, min(2 * BK, K - BK));
+  lstore(I0{}, 0);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 3 <= nk; kt += 3) {
+    step(I0{}, I1{}, kt);
+    step(I1{}, I2{}, kt + 1);
+    step(I2{}, I0{}, kt + 2);
   }
+  if (kt < nk) step(I0{}, I1{}, kt);
+  if (kt + 1 < nk) step(I1{}, I2{}, kt + 1);
 
   // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
 #pragma unroll
@@ -154,30 +178,28 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const bf16* __restrict__ A, 
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
   if (active) {
-    uint4 ra[8], rw[8];
-    auto gload = [&](int k0) {
+    uint4 ra[3][8], rw[3][8];  // three K tiles of loads in flight per wave (tile t in set t % 3)
+    auto gload = [&](auto SET, int k0) {
+      constexpr int S = decltype(SET)::value;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int q = lane + i * 64, row = q >> 3, c = q & 7;
-        ra[i] = ld16(A + (size_t)min(m0 + row, M - 1) * K + k0 + c * 8);
-        rw[i] = ld16(W + (size_t)min(n0 + row, N - 1) * K + k0 + c * 8);
+        ra[S][i] = ld16(A + (size_t)min(m0 + row, M - 1) * K + k0 + c * 8);
+        rw[S][i] = ld16(W + (size_t)min(n0 + row, N - 1) * K + k0 + c * 8);
       }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](auto SET, int buf) {
+      constexpr int S = decltype(SET)::value;
       unsigned char* ba = my + buf * 16384;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int q = lane + i * 64, row = q >> 3, c = q & 7;
         const int off = row * 128 + ((c ^ (row & 7)) << 4);
-        *reinterpret_cast<uint4*>(ba + off) = ra[i];
-        *reinterpret_cast<uint4*>(ba + 8192 + off) = rw[i];
+        *reinterpret_cast<uint4*>(ba + off) = ra[S][i];
+        *reinterpret_cast<uint4*>(ba + 8192 + off) = rw[S][i];
       }
     };
-    gload(kbeg);
-    lstore(0);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < nk) gload(kbeg + (kt + 1) * 64);
+    auto compute = [&](int cur) {
       const unsigned char* ba = my + cur * 16384;
       const unsigned char* bw = ba + 8192;
 #pragma unroll
@@ -195,8 +217,27 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const bf16* __restrict__ A, 
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
-      if (kt + 1 < nk) lstore(cur ^ 1);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    auto step = [&](auto SET, auto NEXT, int t) {  // no workgroup barrier: the LDS region is wave-private
+      gload(SET, kbeg + min((t + 3) * 64, (nk - 1) * 64));  // unconditional: keeps the vmcnt waits counted
+      compute(t & 1);
+      if (t + 1 < nk) lstore(NEXT, (t + 1) & 1);
+    };
+    gload(I0{}, kbeg);
+    gload(I1{}, kbeg + min(64, (nk - 1) * 64));
+    gload(I2{}, kbeg + min(128, (nk - 1) * 64));
+    lstore(I0{}, 0);
+    int kt = 0;
+    for (; kt + 3 <= nk; kt += 3) {
+      step(I0{}, I1{}, kt);
+      step(I1{}, I2{}, kt + 1);
+      step(I2{}, I0{}, kt + 2);
     }
+    if (kt < nk) step(I0{}, I1{}, kt);
+    if (kt + 1 < nk) step(I1{}, I2{}, kt + 1);
   }
 
   auto emit = [&](int m, int n, float x) {
@@ -258,8 +299,11 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
     else gemm_simple_kernel<bf16, bf16, GE_RELU><<<g, 256, 0, s>>>(A, W, bias, (bf16*)C, M, N, K);
     return 0;
   }
+  // alg 0 (default): 128x128 shared tiles when there are enough of them, wave tiles + in-kernel split-K otherwise;
+  // 1 / 2 force one or the other (A/B runs)
   static const int alg = [] { const char* v = getenv("VX_GEMM_ALG"); return v ? atoi(v) : 0; }();
-  if (alg == 1) {  // A/B: the 128x128 shared-tile kernel
+  const long long tiles64 = (long long)((M + 63) / 64) * (N / 64);
+  if (alg == 1 || (alg == 0 && N % 128 == 0 && tiles64 >= 512)) {
     dim3 grid((N + 127) / 128, (M + 127) / 128);
 #define MG(E, F)                                                                                                        \
   do {                                                                                                                  \
@@ -293,7 +337,7 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
     wgemm_kernel<E, F, S><<<mtiles * ngp, 256, lds, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ngr, ngp);             \
   } while (0)
   // split K inside the workgroup when the tile grid alone cannot fill 4 waves on each of the 256 CUs
-  const bool split = (K % 256 == 0) && ((long long)mtiles * (N / 64) < 512);
+  const bool split = (K % 256 == 0) && tiles64 < 512;
   if (split) {
     if (epi == GE_RESID) WG(GE_RESID, true, 4);
     else if (epi == GE_PLAIN) WG(GE_PLAIN, true, 4);
