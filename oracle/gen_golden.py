@@ -116,7 +116,29 @@ def run_case(name: str):
     print(f"[{name}] wrote {os.path.getsize(os.path.join(OUT, name + '.npz')) / 1024:.0f} KiB", flush=True)
 
 
+def run_continual(name: str, prefix_mode: int, S: int, T: int):
+    """valle.py:1139-1238 via bin/infer.py:224-230 (--continual)."""
+    cfg = ModelConfig(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=prefix_mode)
+    sd = synthetic_state_dict(cfg, seed=0)
+    x, x_lens, y = synthetic_inputs(S, T, 8, seed=3)
+    ref = build_reference_model(cfg, sd)
+    with torch.no_grad():
+        codes = ref.continual(x, x_lens, y)
+    m = vo.OracleModel(sd, cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, cfg.prefix_mode, False, 8)
+    assert torch.equal(vo.continual(m, x, x_lens, y), codes), f"{name}: oracle continual differs from the reference"
+    print(f"[{name}] reference continual {tuple(codes.shape)}; oracle == reference", flush=True)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"),
+                        cfg=np.array([128, 2, 2, prefix_mode, 0, 8, 1], dtype=np.int32), weight_seed=np.int32(0),
+                        x=x.numpy().astype(np.int16), x_lens=x_lens.numpy(), y=y.numpy().astype(np.int16),
+                        codes=codes.numpy().astype(np.int16))
+
+
+CONTINUAL = {"continual_mode0": (0, 7, 41), "continual_mode1": (1, 9, 64)}
+
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
-    for c in (sys.argv[1:] or SMALL):
-        run_case(c)
+    for c in (sys.argv[1:] or SMALL + list(CONTINUAL)):
+        if c in CONTINUAL:
+            run_continual(c, *CONTINUAL[c])
+        else:
+            run_case(c)

@@ -366,3 +366,25 @@ def inference_cached(m: OracleModel, x, x_lens, y, enroll_x_lens=None, top_k: in
         return torch.stack(codes, dim=-1).unsqueeze(0)
     codes += m.nar(text, S, prompts, yy[bos:], enroll_x_lens, trace)
     return torch.stack(codes, dim=-1).unsqueeze(0)
+
+
+@torch.no_grad()
+def continual(m: OracleModel, x, x_lens, y) -> torch.Tensor:
+    """VALLE.continual (valle.py:1139-1238): no AR pass — the first half of y (at most 225 frames) is the
+    prompt, codebook 0 of the rest is kept, codebooks 1..7 of the rest are predicted by the NAR stages.
+    The prefix_mode 2/4 text trim is NOT applied here (the reference does not)."""
+    assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3 and y.shape[0] == 1
+    assert torch.all(x_lens > 0)
+    assert m.Q == 8
+    text = x[0]
+    S = int(x_lens.max())
+    prefix_len = min(int(y.shape[1] * 0.5), 3 * 75)
+    prompts = y[0, :prefix_len]
+    codes = [y[0, prefix_len:, 0]]
+    saved = m.prefix_mode
+    try:
+        m.prefix_mode = 0 if saved == 0 else 1  # the NAR body only distinguishes mode 0 from the rest here
+        codes += m.nar(text, S, prompts, y[0, :, 0], None)
+    finally:
+        m.prefix_mode = saved
+    return torch.stack(codes, dim=-1).unsqueeze(0)

@@ -17,8 +17,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
-def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+def golden_names(kind="inference"):
+    names = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    if kind == "continual":
+        return [n for n in names if n.startswith("continual")]
+    return [n for n in names if not n.startswith("continual")]
 
 
 class Golden:
@@ -36,11 +39,13 @@ class Golden:
         self.x = torch.from_numpy(z["x"].astype(np.int64))
         self.x_lens = torch.from_numpy(z["x_lens"])
         self.y = torch.from_numpy(z["y"].astype(np.int64))
+        self.codes = torch.from_numpy(z["codes"].astype(np.int64))
+        if "top_k" not in z:  # VALLE.continual fixtures: inputs + codes only
+            return
         e = int(z["enroll"])
         self.enroll_x_lens = None if e < 0 else torch.tensor([e], dtype=torch.int32)
         self.top_k = int(z["top_k"])
         self.temperature = float(z["temperature"])
-        self.codes = torch.from_numpy(z["codes"].astype(np.int64))
         self.n_pass = int(z["n_pass"])
         self.ar_probe_steps = [int(v) for v in z["ar_probe_steps"]]
         self.ar_probe_logits = torch.from_numpy(z["ar_probe_logits"])

@@ -71,3 +71,10 @@ def test_natural_length_is_16S_plus_1():
 def test_cfg1_fixture_shape():
     g = Golden("cfg1_topk10")
     assert g.codes.shape == (1, 753, 8) and g.cfg.decoder_dim == 1024
+
+
+@pytest.mark.parametrize("name", golden_names("continual"))
+def test_continual_oracle_matches_reference(name):
+    """VALLE.continual (valle.py:1139-1238), SURVEY.md §8(f) rank 1."""
+    g = Golden(name)
+    assert torch.equal(vo.continual(g.oracle(), g.x, g.x_lens, g.y), g.codes)

@@ -166,6 +166,27 @@ class VALLE:
         return codes.unsqueeze(0)
 
 
+    @torch.no_grad()
+    def continual(self, x: torch.Tensor, x_lens: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """VALLE.continual (valle.py:1139-1238; reached by bin/infer.py:224-230 with --continual): the first half
+        of y (at most 225 frames) is the prompt, codebook 0 of the rest is kept and its codebooks 1..7 are
+        predicted by the NAR stages.  Returns (1, T - prefix_len, 8)."""
+        assert x.ndim == 2, x.shape
+        assert x_lens.ndim == 1, x_lens.shape
+        assert y.ndim == 3, y.shape
+        assert y.shape[0] == 1, y.shape
+        assert torch.all(x_lens > 0)
+        assert self.num_quantizers == 8
+        if int(x.min()) < 0 or int(x.max()) >= NUM_TEXT_TOKENS or int(y.min()) < 0 or int(y.max()) >= NUM_AUDIO_TOKENS:
+            raise IndexError("index out of range in self")
+        eng = self.engine()
+        prefix_len = min(int(y.shape[1] * 0.5), 3 * 75)
+        prompts = y[0, :prefix_len, :8].contiguous()
+        rest0 = y[0, prefix_len:, 0].contiguous()
+        codes = eng.nar(x[0], prompts, rest0, out_device=self.device)
+        return codes.unsqueeze(0)
+
+
 def get_model(params) -> VALLE:
     """models/__init__.py:98-136 for --model-name VALL-E; the other model families are outside the hot path."""
     cfg = ModelConfig.from_params(params)
