@@ -47,7 +47,11 @@ def test_two_rank_gloo_matches_single_rank():
     world, per_rank = 2, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    import socket
+
+    with socket.socket() as sk:  # a free port, so concurrent test runs cannot collide
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, q)) for r in range(world)]
     for p in procs:
         p.start()

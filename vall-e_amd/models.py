@@ -42,8 +42,8 @@ class VALLE:
             raise TypeError(f"unexpected arguments {sorted(kwargs)}")
         if not norm_first or add_prenet:
             raise NotImplementedError("post-norm / prenet variants are outside the built scope (DESIGN.md §out of scope)")
-        if nar_scale_factor != 1.0:
-            raise NotImplementedError("nar_scale_factor != 1.0 is outside the built scope (DESIGN.md)")
+        if self.cfg.num_quantizers > 1 and (self.cfg.nar_nhead <= 0 or self.cfg.nar_dim != 64 * self.cfg.nar_nhead):
+            raise NotImplementedError("nar_scale_factor must keep the NAR head_dim at 64 (DESIGN.md)")
         self.ar_audio_prepend_bos = self.cfg.prepend_bos
         self.num_quantizers = self.cfg.num_quantizers
         self.prefix_mode = prefix_mode
