@@ -75,6 +75,7 @@ typedef struct vx_config {
   int32_t max_audio;       /* capacity: audio rows = [BOS] + prompt frames + generated frames */
   int32_t device;          /* HIP device ordinal */
   int32_t flags;           /* enum vx_flags */
+  int32_t max_batch;       /* slots for batched AR decode (vx_batch_*): 0/1 = batch-1 only, <= 32; bf16 only */
 } vx_config;
 
 /* Sampling / stop-rule parameters of one AR decode (VALLE.inference args top_k, temperature,
@@ -128,6 +129,19 @@ int vx_ar_result(vx_engine* e, int64_t* tokens, int32_t capacity, int32_t* n_tok
 int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
            const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream);
 
+/* ---- batched AR decode (BASELINE configs[2]): up to max_batch utterances ("slots") advance one token per
+ * step and share one stream of the weights; every slot has its own padded KV cache, stop rule and sampler
+ * (the reference is batch-1, valle.py:989: each slot reproduces one independent inference() call).
+ * vx_batch_prefill = vx_ar_prefill into a slot; vx_batch_decode runs the shared step until every one of
+ * slots [0, n_slots) has stopped (params[i] for slot i; exp_noise / forced must be DEVICE pointers that stay
+ * valid during the call); vx_batch_result = vx_ar_result of a slot.  The NAR stages then run per utterance
+ * with vx_nar. */
+int vx_batch_prefill(vx_engine* e, int32_t slot, const int64_t* text, int32_t S, const int64_t* prompt_cb0, int32_t P,
+                     void* stream);
+int vx_batch_decode(vx_engine* e, int32_t n_slots, const vx_decode_params* params, void* stream);
+int vx_batch_result(vx_engine* e, int32_t slot, int64_t* tokens, int32_t capacity, int32_t* n_tokens,
+                    int32_t* stop_reason);
+
 /* Device-time of the last calls, measured with HIP events on the engine's stream:
  * out[0] prefill ms, out[1] AR decode ms, out[2] NAR ms, out[3] AR passes, out[4] graph launches. */
 int vx_get_timings(vx_engine* e, double* out, int32_t n);
@@ -135,7 +149,9 @@ int vx_get_timings(vx_engine* e, double* out, int32_t n);
 /* Parity-test taps: copies an internal buffer to host memory (synchronises the engine stream).
  * names: "ar_logits" (n_pass x 1025 fp32 with VX_FLAG_TRACE_LOGITS, else the last row),
  * "ar_sampled" / "ar_argmax" (int32 per pass), "nar_logits" (T x 1024 fp32 of the last stage),
- * "ar_x" (d fp32 residual stream of the last AR row), "nar_x" (N x d fp32 after the last stage). */
+ * "ar_x" (d fp32 residual stream of the last AR row), "nar_x" (N x d fp32 after the last stage),
+ * "batch_logits" (32 x 1088 fp32: newest logits row of every slot), "batch_argmax" / "batch_sampled"
+ * (32 x (max_audio+2) int32 per pass). */
 int vx_read_buffer(vx_engine* e, const char* name, void* dst, int64_t offset_bytes, int64_t nbytes);
 
 /* Kernel-level entry points (device pointers, fp32 unless noted) used by tests/ to check each

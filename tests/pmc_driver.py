@@ -23,7 +23,7 @@ def ck(rc):
 
 class Cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("struct_size d_model nhead num_layers nar_d_model nar_nhead nar_num_layers "
-                                         "num_quantizers prefix_mode prepend_bos precision max_text max_audio device flags").split()]
+                                         "num_quantizers prefix_mode prepend_bos precision max_text max_audio device flags max_batch").split()]
 
 
 class Dec(C.Structure):
@@ -80,7 +80,7 @@ def keys():
         yield f"nar_stage_embeddings.{j}.word_embeddings.weight", (1, d)
 
 
-c = Cfg(C.sizeof(Cfg), d, H, L, d, H, L, Q, 1, 0, 1, 64, 1024, 0, 2)  # bf16, flags: VX_FLAG_NO_GRAPH
+c = Cfg(C.sizeof(Cfg), d, H, L, d, H, L, Q, 1, 0, 1, 64, 1024, 0, 2, 0)  # bf16, flags: VX_FLAG_NO_GRAPH
 h = C.c_void_p()
 ck(lib.vx_create(C.byref(c), C.byref(h)))
 rng = np.random.default_rng(0)

@@ -35,7 +35,7 @@ def test_struct_sizes_match_header(lib):
     from valle_amd.engine import VxConfig, VxDecodeParams
     import ctypes as C
 
-    assert C.sizeof(VxConfig) == 15 * 4
+    assert C.sizeof(VxConfig) == 16 * 4
     assert C.sizeof(VxDecodeParams) == 56
 
 

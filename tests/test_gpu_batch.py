@@ -1,0 +1,134 @@
+"""GPU: batched AR decode (BASELINE configs[2]) — every slot must behave like an independent batch-1
+inference() of the reference.  The batched step computes its GEMMs on MFMA with bf16 activations, so the
+check against the fp32 oracle is teacher-forced (argmax agreement / final logits within the bf16
+tolerance), plus exact properties: slot independence, determinism, per-slot stop rule."""
+import pytest
+import torch
+
+from conftest import Golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(max_batch=4, d=256, nhead=4, L=4, **kw):
+    import __graft_entry__ as ge
+
+    ge.build()
+    from valle_amd.config import ModelConfig
+    from valle_amd.models import VALLE
+    from valle_amd.weights import synthetic_state_dict
+
+    cfg = ModelConfig(decoder_dim=d, nhead=nhead, num_decoder_layers=L, prefix_mode=1)
+    sd = synthetic_state_dict(cfg, 0)
+    m = VALLE(d, nhead, L, prefix_mode=1, precision="bf16", max_text=64, max_audio=700, print_eos=False, max_batch=max_batch, **kw)
+    m.load_state_dict(sd)
+    return cfg, sd, m.to("cuda:0").eval()
+
+
+def _utts(shapes):
+    from valle_amd.weights import synthetic_inputs
+
+    return [synthetic_inputs(S, P, 8, seed=10 + i) for i, (S, P) in enumerate(shapes)]
+
+
+def test_batch_teacher_forced_against_fp32_oracle():
+    from oracle import valle_oracle as vo
+
+    cfg, sd, m = _setup(max_batch=4)
+    eng = m.engine()
+    utts = _utts([(6, 30), (9, 12), (4, 55)])
+    om = vo.OracleModel(sd, cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, 1, False, 8)
+    refs = []
+    for b, (x, xl, y) in enumerate(utts):
+        tr = {}
+        codes = vo.inference_cached(om, x, xl, y, None, 1, 1.0, None, trace=tr, skip_nar=True)  # greedy reference tokens
+        refs.append((codes[0, :, 0].contiguous(), torch.stack(tr["ar_logits"])))
+        eng.batch_prefill(b, x[0], y[0, :, 0].contiguous())
+    eng.batch_decode(3, top_k=1, forced=[r[0].cuda() for r in refs])
+    stride = eng.max_audio + 2
+    arg = eng.read("batch_argmax", (32, stride), dtype=torch.int32)
+    lg = eng.read("batch_logits", (32, 1088))
+    for b, (toks, ref_logits) in enumerate(refs):
+        got_toks, reason = eng.batch_result(b)
+        assert torch.equal(got_toks, toks) and reason == 4  # forced tokens appended, closed by the forcing limit
+        n = toks.numel()
+        ref_arg = ref_logits.argmax(1)  # passes 0..n-1 (the oracle stops before computing pass n)
+        agree = (arg[b, :n].long() == ref_arg[:n]).float().mean().item()
+        assert agree >= 0.97, (b, agree)
+        # newest logits row = pass n (after the last forced token); the oracle's last traced pass is n-1, so compare
+        # that one through a second decode below; here only finiteness / scale
+        assert torch.isfinite(lg[b, :1025]).all()
+
+
+def test_batch_last_logits_within_bf16_tolerance():
+    from oracle import valle_oracle as vo
+
+    cfg, sd, m = _setup(max_batch=2)
+    eng = m.engine()
+    utts = _utts([(5, 20), (7, 33)])
+    om = vo.OracleModel(sd, cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, 1, False, 8)
+    K = 25
+    want = []
+    for b, (x, xl, y) in enumerate(utts):
+        tr = {}
+        codes = vo.inference_cached(om, x, xl, y, None, 1, 1.0, None, trace=tr, skip_nar=True)
+        toks = codes[0, :K, 0].contiguous()
+        tr2 = {}
+        vo.inference_cached(om, x, xl, y, None, 1, 1.0, None, trace=tr2, forced=toks, skip_nar=True)
+        want.append((toks, tr2["ar_logits"][K]))  # logits after K forced tokens
+        eng.batch_prefill(b, x[0], y[0, :, 0].contiguous())
+    eng.batch_decode(2, top_k=1, forced=[w[0].cuda() for w in want])
+    lg = eng.read("batch_logits", (32, 1088))
+    for b, (toks, ref) in enumerate(want):
+        err = float((lg[b, :1025] - ref).abs().max())
+        assert err <= 0.03 * float(ref.abs().max()), (b, err)
+
+
+def test_slots_are_independent_and_deterministic():
+    cfg, sd, m = _setup(max_batch=4)
+    u = _utts([(6, 30), (9, 12), (4, 55), (5, 8)])
+    a = m.inference_batch([u[0], u[1], u[2]], top_k=5, seeds=[11, 22, 33])
+    b = m.inference_batch([u[0], u[3]], top_k=5, seeds=[11, 44])
+    c = m.inference_batch([u[0], u[1], u[2]], top_k=5, seeds=[11, 22, 33])
+    assert torch.equal(a[0], b[0])  # slot 0 does not depend on what the other slots hold
+    for x, y in zip(a, c):
+        assert torch.equal(x, y)  # bitwise reproducible
+    for codes, (x, xl, y) in zip(a, u[:3]):
+        assert codes.shape == (1, 16 * x.shape[1] + 1, 8)  # every slot stops by its own length rule (valle.py:1047)
+        assert int(codes.min()) >= 0 and int(codes.max()) < 1024
+
+
+def test_batch_matches_batch1_engine_under_teacher_forcing():
+    """Same bf16 weights, same forced tokens: the batched step's per-pass argmax agrees with the batch-1 step's."""
+    cfg, sd, m = _setup(max_batch=2, trace_logits=False)
+    eng = m.engine()
+    (x, xl, y), (x2, xl2, y2) = _utts([(6, 30), (8, 17)])
+    # batch-1 greedy run gives the tokens and its own per-pass argmax
+    eng.ar_prefill(x[0], y[0, :, 0].contiguous())
+    eng.ar_decode(top_k=1)
+    toks, _, n_pass = eng.ar_result()
+    arg1 = eng.read("ar_argmax", (n_pass,), dtype=torch.int32)
+    eng.batch_prefill(0, x[0], y[0, :, 0].contiguous())
+    eng.batch_prefill(1, x2[0], y2[0, :, 0].contiguous())
+    eng.batch_decode(2, top_k=1, forced=[toks.cuda(), toks[:5].cuda()])
+    arg = eng.read("batch_argmax", (32, eng.max_audio + 2), dtype=torch.int32)
+    agree = (arg[0, :n_pass] == arg1).float().mean().item()
+    assert agree >= 0.97, agree
+
+
+@pytest.mark.parametrize("B", [8, 32])
+def test_full_batch_cfg1_geometry(B):
+    """d=1024 L=12, B slots with ragged S in [40, 54]: shapes, ranges, per-slot lengths."""
+    cfg, sd, m = _setup(max_batch=32, d=1024, nhead=16, L=12)
+    shapes = [(40 + (i * 5) % 15, 225 if i % 2 == 0 else 150) for i in range(B)]
+    u = _utts(shapes)
+    eng = m.engine()
+    for b, (x, xl, y) in enumerate(u):
+        eng.batch_prefill(b, x[0], y[0, :, 0].contiguous())
+    eng.batch_decode(B, top_k=10, seeds=list(range(1, B + 1)), max_new_tokens=48)
+    for b in range(B):
+        toks, reason = eng.batch_result(b)
+        assert toks.numel() == 48 and reason == 4
+        assert int(toks.min()) >= 0 and int(toks.max()) < 1024
+    t = eng.timings()
+    print("batch", B, "step_us", 1e3 * t["batch_decode_ms"] / t["batch_launches"], "tok/s", B * t["batch_launches"] / (t["batch_decode_ms"] * 1e-3))

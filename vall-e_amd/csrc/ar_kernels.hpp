@@ -352,6 +352,8 @@ struct SampleArgs {
   const float* pe;       // sine table (pe_rows, d) fp32
   float* x;              // (d,) residual stream input of the next pass
   int d;
+  // batched decode: workgroup = slot; per-slot strides (0 in the batch-1 step, grid = 1)
+  int logits_stride, tok_stride;
 };
 
 __device__ __forceinline__ uint32_t order_key(float v) {
@@ -388,12 +390,17 @@ __device__ __forceinline__ uint32_t kth_largest_1reg(uint32_t x, int k) {
 // depends on is a wave-level DPP reduction or a ballot — no LDS, no barrier on the token's critical path.
 template <int NV>
 __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
-  ArState* st = a.st;
+  const int slot = blockIdx.x;
+  ArState* st = a.st + slot;
   if (st->done) return;  // uniform
   const int lane = threadIdx.x;
   const int V = a.V;
   const int pass = st->pass;
-  const float* lg = a.logits;  // newest row, fixed address
+  const float* lg = a.logits + (size_t)slot * a.logits_stride;  // newest row, fixed address
+  int* const tokens = a.tokens + (size_t)slot * a.tok_stride;
+  int* const sampled = a.sampled + (size_t)slot * a.tok_stride;
+  int* const argmaxes = a.argmaxes + (size_t)slot * a.tok_stride;
+  float* const xout = a.x + (size_t)slot * a.d;
   const float* nz = st->exp_noise;
   if (nz != nullptr) nz += (size_t)min((long long)pass, st->noise_rows - 1) * V;
   float v[NV], qn[NV];
@@ -532,9 +539,9 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
     else if (max_new >= 0 && n_gen + 1 >= max_new) { reason = 4; go = false; }
   }
   if (lane == 0) {
-    a.sampled[pass] = sm.i;
-    a.argmaxes[pass] = am.i;
-    if (append) { a.tokens[n_gen] = tok; st->n_gen = n_gen + 1; }
+    sampled[pass] = sm.i;
+    argmaxes[pass] = am.i;
+    if (append) { tokens[n_gen] = tok; st->n_gen = n_gen + 1; }
     if (reason != 0) { st->done = 1; st->stop_reason = reason; }
     if (go) { st->row = row; st->pass = pass + 1; }
   }
@@ -547,7 +554,7 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
     float4 o;
     o.x = __fadd_rn(ev.x, __fmul_rn(alpha, pv.x)); o.y = __fadd_rn(ev.y, __fmul_rn(alpha, pv.y));
     o.z = __fadd_rn(ev.z, __fmul_rn(alpha, pv.z)); o.w = __fadd_rn(ev.w, __fmul_rn(alpha, pv.w));
-    *reinterpret_cast<float4*>(a.x + c) = o;
+    *reinterpret_cast<float4*>(xout + c) = o;
   }
 }
 

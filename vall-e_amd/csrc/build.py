@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "libvallex.so")
 SRCS = ["engine.hip"]
-DEPS = SRCS + ["common.hpp", "ar_kernels.hpp", "rows_kernels.hpp", "mfma_kernels.hpp", "../../include/vallex.h", "build.py"]
+DEPS = SRCS + ["common.hpp", "ar_kernels.hpp", "rows_kernels.hpp", "mfma_kernels.hpp", "batch_kernels.hpp", "../../include/vallex.h", "build.py"]
 
 
 def stale() -> bool:

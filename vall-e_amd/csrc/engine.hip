@@ -16,6 +16,7 @@
 #include "ar_kernels.hpp"
 #include "rows_kernels.hpp"
 #include "mfma_kernels.hpp"
+#include "batch_kernels.hpp"
 
 using namespace vx;
 
@@ -95,6 +96,19 @@ struct vx_engine {
   int vt_ld = 0;
   float *yemb = nullptr, *nar_logits = nullptr, *ada = nullptr;
   long long *ids_text = nullptr, *ids_audio = nullptr, *ids_prompts = nullptr, *ids_samples = nullptr, *d_codes = nullptr;
+  // batched decode (slots)
+  int bmax = 0;
+  float *bx = nullptr, *bq = nullptr, *bpart = nullptr, *blogits = nullptr;
+  vx::bf16 *bh = nullptr, *batt = nullptr, *bff = nullptr, *bkv = nullptr;
+  size_t bkv_slot = 0;  // elements per slot
+  ArState* bst = nullptr;    // device, BMAX
+  ArState* h_bst = nullptr;  // pinned: [0..BMAX) staging, [BMAX..3*BMAX) two poll slots
+  int *btok = nullptr, *bsamp = nullptr, *bargm = nullptr;
+  int btok_stride = 0;
+  std::unordered_map<int, hipGraphExec_t> bgraphs;
+  int bS[BMAX] = {}, bP[BMAX] = {}, bbos[BMAX] = {}, bngen[BMAX] = {}, breason[BMAX] = {};
+  bool bprefilled[BMAX] = {};
+  double t_bdecode = 0, n_blaunch = 0;
   // graph
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
@@ -199,6 +213,9 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
     return fail(VX_ERR_UNSUPPORTED, "d_model must be a multiple of 64 and <= 1024");
   if (c.max_text <= 0 || c.max_audio <= 0) return fail(VX_ERR_ARG, "capacities must be positive");
   if (c.precision != VX_PREC_F32 && c.precision != VX_PREC_BF16) return fail(VX_ERR_ARG, "bad precision");
+  if (c.max_batch < 0 || c.max_batch > BMAX) return fail(VX_ERR_ARG, "max_batch must be 0..%d", BMAX);
+  if (c.max_batch > 1 && (c.precision != VX_PREC_BF16 || c.d_model % 128))
+    return fail(VX_ERR_UNSUPPORTED, "batched decode needs bf16 precision and d_model % 128 == 0");
 
   HIPC(hipSetDevice(c.device));
   vx_engine* e = new vx_engine();
@@ -254,6 +271,30 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   VXC(dalloc_t(e, &e->ids_prompts, (size_t)c.max_audio * 8));
   VXC(dalloc_t(e, &e->ids_samples, (size_t)c.max_audio));
   VXC(dalloc_t(e, &e->d_codes, (size_t)c.max_audio * 8));
+  if (c.max_batch > 1) {
+    e->bmax = c.max_batch;
+    e->btok_stride = c.max_audio + 2;
+    e->bkv_slot = (size_t)c.num_layers * 2 * H * e->ctx_max * hd;
+    VXC(dalloc_t(e, &e->bx, (size_t)BMAX * d));
+    VXC(dalloc_t(e, &e->bq, (size_t)BMAX * d));
+    VXC(dalloc_t(e, &e->bpart, (size_t)4 * BMAX * d));
+    VXC(dalloc_t(e, &e->blogits, (size_t)BMAX * LOGITS_CUR));
+    VXC(dalloc_t(e, &e->bh, (size_t)BMAX * d));
+    VXC(dalloc_t(e, &e->batt, (size_t)BMAX * d));
+    VXC(dalloc_t(e, &e->bff, (size_t)BMAX * 4 * d));
+    VXC(dalloc_t(e, &e->bkv, (size_t)e->bmax * e->bkv_slot));
+    VXC(dalloc_t(e, &e->bst, (size_t)BMAX));
+    VXC(dalloc_t(e, &e->btok, (size_t)BMAX * e->btok_stride));
+    VXC(dalloc_t(e, &e->bsamp, (size_t)BMAX * e->btok_stride));
+    VXC(dalloc_t(e, &e->bargm, (size_t)BMAX * e->btok_stride));
+    HIPC(hipHostMalloc((void**)&e->h_bst, 3 * BMAX * sizeof(ArState)));
+    // MFMA A operands always read 32 rows: rows of unused slots must hold finite values
+    HIPC(hipMemset(e->bx, 0, (size_t)BMAX * d * 4));
+    HIPC(hipMemset(e->bh, 0, (size_t)BMAX * d * 2));
+    HIPC(hipMemset(e->batt, 0, (size_t)BMAX * d * 2));
+    HIPC(hipMemset(e->bff, 0, (size_t)BMAX * 4 * d * 2));
+    HIPC(hipMemset(e->bst, 0, (size_t)BMAX * sizeof(ArState)));
+  }
   if (c.num_quantizers > 1)
     VXC(dalloc_t(e, &e->ada, (size_t)(c.num_quantizers - 1) * (2 * c.nar_num_layers + 1) * 2 * dn));
   // weights
@@ -269,6 +310,8 @@ extern "C" void vx_destroy(vx_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
   if (e->es) (void)hipStreamSynchronize(e->es);
+  for (auto& kvp : e->bgraphs) (void)hipGraphExecDestroy(kvp.second);
+  if (e->h_bst) (void)hipHostFree(e->h_bst);
   if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
   if (e->graph) (void)hipGraphDestroy(e->graph);
   for (void* p : e->allocs) (void)hipFree(p);
@@ -464,7 +507,8 @@ static int attn_rows(vx_engine* e, const void* qkv, void* out, int M, int d, int
 // plain LayerNorm (AR); otherwise the stage's AdaLN vectors.  If kv_layer0 is non-null the K/V
 // rows are also scattered into the decode cache.
 static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int d, int H, int text_len, int ada_stage,
-                     bool fill_cache) {
+                     bool fill_cache, char* kv_base = nullptr) {
+  if (kv_base == nullptr) kv_base = (char*)e->kv;
   const size_t kv_layer = (size_t)2 * H * e->ctx_max * 64 * e->esz;
   for (size_t li = 0; li < layers.size(); ++li) {
     const LayerW& l = layers[li];
@@ -476,7 +520,7 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
     VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d));
     VXC(gemm_rows(e, e->Hn, l.in_w, l.in_b, e->QKV, M, 3 * d, d, GE_BIAS, false, use_mfma(e)));
     if (fill_cache) {
-      char* kc = (char*)e->kv + li * kv_layer;
+      char* kc = kv_base + li * kv_layer;
       char* vc = kc + kv_layer / 2;
       if (e->bf16) kv_scatter_kernel<bf16><<<M, 256, 0, e->es>>>((const bf16*)e->QKV, (bf16*)kc, (bf16*)vc, M, d, 64, e->ctx_max);
       else kv_scatter_kernel<float><<<M, 256, 0, e->es>>>((const float*)e->QKV, (float*)kc, (float*)vc, M, d, 64, e->ctx_max);
@@ -507,23 +551,25 @@ static int sync_out(vx_engine* e, void* stream) {
 }
 
 // ------------------------------------------------------------------------------ AR
-static int enqueue_head(vx_engine* e, hipStream_t s) {
+static int enqueue_head(vx_engine* e, hipStream_t s, const float* x = nullptr, float* logits = nullptr,
+                        const ArState* st = nullptr) {
   const vx_config& c = e->cfg;
   GemvArgs a{};
   a.W = W<void>(e, "ar_predict_layer.weight");
   a.bias = nullptr;
-  a.x = e->ar_x;
+  a.x = x ? x : e->ar_x;
   a.gamma = W<float>(e, "ar_decoder.norm.weight");
   a.beta = W<float>(e, "ar_decoder.norm.bias");
-  a.y = e->ar_logits;
+  a.y = logits ? logits : e->ar_logits;
   a.N = AR_VOCAB; a.K = c.d_model;
   a.pro = PRO_LN; a.epi = EPI_LOGITS;
-  a.st = e->d_st;
+  a.st = st ? st : e->d_st;
   return launch_gemv(e->bf16, a, e->num_cu, s);
 }
 
-extern "C" int vx_ar_prefill(vx_engine* e, const int64_t* text, int32_t S, const int64_t* prompt_cb0, int32_t P,
-                             void* stream) {
+// Shared by vx_ar_prefill (slot < 0: the batch-1 buffers) and vx_batch_prefill (slot >= 0).
+static int prefill_impl(vx_engine* e, int slot, const int64_t* text, int32_t S, const int64_t* prompt_cb0, int32_t P,
+                        void* stream) {
   if (!e || !text || (!prompt_cb0 && P > 0)) return fail(VX_ERR_ARG, "null argument");
   if (!e->finalized) return fail(VX_ERR_STATE, "weights not finalized");
   if (S <= 0 || P < 0) return fail(VX_ERR_ARG, "S must be > 0 (valle.py:991), P >= 0");
@@ -531,6 +577,7 @@ extern "C" int vx_ar_prefill(vx_engine* e, const int64_t* text, int32_t S, const
   const int bos = c.prepend_bos ? 1 : 0, A = bos + P, M = S + A, d = c.d_model;
   if (S > c.max_text || A + 1 > c.max_audio) return fail(VX_ERR_CAPACITY, "S=%d / P=%d exceed capacity", S, P);
   if (A == 0) return fail(VX_ERR_ARG, "empty audio prefix needs prepend_bos");
+  if (slot >= e->bmax) return fail(VX_ERR_ARG, "slot %d >= max_batch %d", slot, e->bmax);
   HIPC(hipSetDevice(c.device));
   VXC(sync_in(e, stream));
   HIPC(hipEventRecord(e->ev_t[0], e->es));
@@ -544,27 +591,48 @@ extern "C" int vx_ar_prefill(vx_engine* e, const int64_t* text, int32_t S, const
                                          W<float>(e, "ar_text_position.alpha"), e->pe_ar, 0, e->X, S);
   embed_pos_kernel<<<A, 256, 0, e->es>>>(e->ids_audio, 1, 0, W<float>(e, "ar_audio_embedding.word_embeddings.weight"), 1025 + bos, d,
                                          W<float>(e, "ar_audio_position.alpha"), e->pe_ar, 0, e->X + (size_t)S * d, A);
-  VXC(run_stack(e, e->ar_l, M, d, c.nhead, S, -1, true));
-  HIPC(hipMemcpyAsync(e->ar_x, e->X + (size_t)(M - 1) * d, (size_t)d * 4, hipMemcpyDeviceToDevice, e->es));
+  char* kv_base = slot < 0 ? (char*)e->kv : (char*)(e->bkv + (size_t)slot * e->bkv_slot);
+  float* x_dst = slot < 0 ? e->ar_x : e->bx + (size_t)slot * d;
+  float* lg_dst = slot < 0 ? e->ar_logits : e->blogits + (size_t)slot * LOGITS_CUR;
+  ArState* st_dst = slot < 0 ? e->d_st : e->bst + slot;
+  VXC(run_stack(e, e->ar_l, M, d, c.nhead, S, -1, true, kv_base));
+  HIPC(hipMemcpyAsync(x_dst, e->X + (size_t)(M - 1) * d, (size_t)d * 4, hipMemcpyDeviceToDevice, e->es));
   // decode state as of "pass 0 computed"
-  ArState& st = e->h_st[0];
+  ArState& st = slot < 0 ? e->h_st[0] : e->h_bst[slot];
   memset(&st, 0, sizeof st);
   st.S = S; st.bos = bos; st.P = P; st.row = M - 1; st.pass = 0;
   st.temperature = 1.0f; st.max_new = -1;
-  st.trace_logits = (c.flags & VX_FLAG_TRACE_LOGITS) ? 1 : 0;
-  HIPC(hipMemcpyAsync(e->d_st, &st, sizeof st, hipMemcpyHostToDevice, e->es));
-  VXC(enqueue_head(e, e->es));
+  st.trace_logits = (slot < 0 && (c.flags & VX_FLAG_TRACE_LOGITS)) ? 1 : 0;
+  HIPC(hipMemcpyAsync(st_dst, &st, sizeof st, hipMemcpyHostToDevice, e->es));
+  VXC(enqueue_head(e, e->es, x_dst, lg_dst, st_dst));
   HIPC(hipGetLastError());
   HIPC(hipEventRecord(e->ev_t[1], e->es));
-  HIPC(hipStreamSynchronize(e->es));  // h_st[0] staging is reused by decode
+  HIPC(hipStreamSynchronize(e->es));  // the staging state is reused by decode
   float ms = 0.f;
   HIPC(hipEventElapsedTime(&ms, e->ev_t[0], e->ev_t[1]));
   e->t_prefill = ms;
-  e->S = S; e->P = P; e->bos = bos;
-  e->prefilled = true; e->decoded = false;
-  e->n_gen = 0; e->n_pass = 1; e->stop_reason = 0;
+  if (slot < 0) {
+    e->S = S; e->P = P; e->bos = bos;
+    e->prefilled = true; e->decoded = false;
+    e->n_gen = 0; e->n_pass = 1; e->stop_reason = 0;
+  } else {
+    e->bS[slot] = S; e->bP[slot] = P; e->bbos[slot] = bos;
+    e->bprefilled[slot] = true; e->bngen[slot] = 0; e->breason[slot] = 0;
+  }
   VXC(sync_out(e, stream));
   return VX_OK;
+}
+
+extern "C" int vx_ar_prefill(vx_engine* e, const int64_t* text, int32_t S, const int64_t* prompt_cb0, int32_t P,
+                             void* stream) {
+  return prefill_impl(e, -1, text, S, prompt_cb0, P, stream);
+}
+
+extern "C" int vx_batch_prefill(vx_engine* e, int32_t slot, const int64_t* text, int32_t S, const int64_t* prompt_cb0,
+                                int32_t P, void* stream) {
+  if (!e) return fail(VX_ERR_ARG, "null engine");
+  if (slot < 0 || slot >= e->bmax) return fail(VX_ERR_ARG, "slot %d outside [0, max_batch=%d)", slot, e->bmax);
+  return prefill_impl(e, slot, text, S, prompt_cb0, P, stream);
 }
 
 // One decode step: sample from the newest logits, append, run the 12-layer stack on the new
@@ -731,6 +799,184 @@ extern "C" int vx_ar_result(vx_engine* e, int64_t* tokens, int32_t capacity, int
   return VX_OK;
 }
 
+// ------------------------------------------------------------------------------ batched AR decode
+template <int EPI> static int launch_bgemm(const BgemmArgs& a, hipStream_t s) {
+  const int ns = a.K / (a.kgroups * 128);
+  const int grid = ((a.N + 15) / 16) * a.kgroups;
+  if (ns * a.kgroups * 128 != a.K) return fail(VX_ERR_UNSUPPORTED, "bgemm: K=%d kgroups=%d", a.K, a.kgroups);
+  if (ns == 1) bgemm_kernel<EPI, 1><<<grid, 256, 0, s>>>(a);
+  else if (ns == 2) bgemm_kernel<EPI, 2><<<grid, 256, 0, s>>>(a);
+  else if (ns == 4) bgemm_kernel<EPI, 4><<<grid, 256, 0, s>>>(a);
+  else if (ns == 8) bgemm_kernel<EPI, 8><<<grid, 256, 0, s>>>(a);
+  else return fail(VX_ERR_UNSUPPORTED, "bgemm: %d steps per wave", ns);
+  return VX_OK;
+}
+static int kgroups_for(int K) { return (K / 128) >= 4 ? 4 : 1; }
+
+// One batched step: every slot samples its next token, then the L layers run once over all B slots.
+static int enqueue_batch_step(vx_engine* e, int B, hipStream_t s) {
+  const vx_config& c = e->cfg;
+  const int d = c.d_model, H = c.nhead, hd = 64, L = c.num_layers;
+  SampleArgs sa{};
+  sa.logits = e->blogits; sa.V = AR_VOCAB; sa.st = e->bst;
+  sa.tokens = e->btok; sa.sampled = e->bsamp; sa.argmaxes = e->bargm;
+  sa.emb = W<float>(e, "ar_audio_embedding.word_embeddings.weight");
+  sa.alpha = W<float>(e, "ar_audio_position.alpha");
+  sa.pe = e->pe_ar; sa.x = e->bx; sa.d = d;
+  sa.logits_stride = LOGITS_CUR; sa.tok_stride = e->btok_stride;
+  sample_embed_kernel<17><<<B, 64, 0, s>>>(sa);
+  const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd;  // elements
+  const float scale = 1.0f / sqrtf((float)hd);
+  const int lnb = (B + 3) / 4;
+  const int kg_d = kgroups_for(d), kg_ff = kgroups_for(4 * d);
+  for (int li = 0; li < L; ++li) {
+    const LayerW& l = e->ar_l[li];
+    // LN1 (+ the FFN2 partial sums of the previous layer)
+    const bool prev = li > 0;
+    ln_batch_kernel<<<lnb, 256, 0, s>>>(e->bx, prev ? e->bpart : nullptr, kg_ff, prev ? e->ar_l[li - 1].b2 : nullptr,
+                                        l.n1_g, l.n1_b, e->bh, B, d);
+    BgemmArgs a{};
+    a.st = e->bst; a.B = B; a.d = d; a.hd = hd; a.ctx_max = e->ctx_max;
+    a.A = e->bh; a.W = (const bf16*)l.in_w; a.bias = l.in_b; a.N = 3 * d; a.K = d; a.kgroups = 1;
+    a.q = e->bq; a.kv = e->bkv + (size_t)li * kv_layer; a.kv_slot_stride = e->bkv_slot; a.kv_v_offset = kv_layer / 2;
+    VXC(launch_bgemm<BE_QKV>(a, s));
+    attn_batch_kernel<64><<<dim3(H, B), 256, 0, s>>>(e->bq, e->bkv + (size_t)li * kv_layer, e->bkv_slot, kv_layer / 2, e->bst,
+                                                     e->ctx_max, d, scale, e->batt);
+    BgemmArgs o{};
+    o.st = e->bst; o.B = B;
+    o.A = e->batt; o.W = (const bf16*)l.out_w; o.N = d; o.K = d; o.kgroups = kg_d; o.part = e->bpart;
+    VXC(launch_bgemm<BE_PARTIAL>(o, s));
+    ln_batch_kernel<<<lnb, 256, 0, s>>>(e->bx, e->bpart, kg_d, l.out_b, l.n2_g, l.n2_b, e->bh, B, d);
+    BgemmArgs f{};
+    f.st = e->bst; f.B = B;
+    f.A = e->bh; f.W = (const bf16*)l.w1; f.bias = l.b1; f.N = 4 * d; f.K = d; f.kgroups = 1; f.f = e->bff;
+    VXC(launch_bgemm<BE_RELU>(f, s));
+    BgemmArgs g{};
+    g.st = e->bst; g.B = B;
+    g.A = e->bff; g.W = (const bf16*)l.w2; g.N = d; g.K = 4 * d; g.kgroups = kg_ff; g.part = e->bpart;
+    VXC(launch_bgemm<BE_PARTIAL>(g, s));
+  }
+  ln_batch_kernel<<<lnb, 256, 0, s>>>(e->bx, e->bpart, kg_ff, e->ar_l[L - 1].b2, W<float>(e, "ar_decoder.norm.weight"),
+                                      W<float>(e, "ar_decoder.norm.bias"), e->bh, B, d);
+  BgemmArgs hgm{};
+  hgm.st = e->bst; hgm.B = B;
+  hgm.A = e->bh; hgm.W = W<bf16>(e, "ar_predict_layer.weight"); hgm.N = AR_VOCAB; hgm.K = d; hgm.kgroups = 1;
+  hgm.logits = e->blogits; hgm.logits_stride = LOGITS_CUR;
+  VXC(launch_bgemm<BE_LOGITS>(hgm, s));
+  return VX_OK;
+}
+
+extern "C" int vx_batch_decode(vx_engine* e, int32_t B, const vx_decode_params* params, void* stream) {
+  if (!e || !params) return fail(VX_ERR_ARG, "null argument");
+  if (B < 1 || B > e->bmax) return fail(VX_ERR_ARG, "n_slots %d outside [1, max_batch=%d]", B, e->bmax);
+  const vx_config& c = e->cfg;
+  HIPC(hipSetDevice(c.device));
+  long long bound = 1;
+  for (int b = 0; b < B; ++b) {
+    const vx_decode_params& p = params[b];
+    if (p.struct_size != (int32_t)sizeof(vx_decode_params)) return fail(VX_ERR_ARG, "vx_decode_params.struct_size mismatch");
+    if (!e->bprefilled[b]) return fail(VX_ERR_STATE, "slot %d needs a fresh vx_batch_prefill", b);
+    if (!(p.temperature > 0.f)) return fail(VX_ERR_ARG, "temperature must be > 0");
+    long long max_tok = 16LL * e->bS[b] + 1 - e->bbos[b];
+    if (p.forced) max_tok = p.n_forced;
+    else if (p.max_new_tokens >= 0 && p.max_new_tokens < max_tok) max_tok = p.max_new_tokens;
+    if (e->bbos[b] + e->bP[b] + max_tok > c.max_audio) return fail(VX_ERR_CAPACITY, "slot %d needs %lld audio rows, capacity %d", b, e->bbos[b] + e->bP[b] + max_tok, c.max_audio);
+    const long long steps = max_tok + (p.forced ? 1 : 0);
+    if (steps > bound) bound = steps;
+    ArState& st = e->h_bst[b];
+    st.top_k = p.top_k; st.temperature = p.temperature; st.max_new = p.max_new_tokens;
+    st.exp_noise = p.exp_noise; st.noise_rows = p.noise_rows; st.seed = p.seed;
+    st.forced = p.forced ? (p.n_forced > 0 ? (const long long*)p.forced : (const long long*)e->btok) : nullptr;
+    st.n_forced = p.forced ? p.n_forced : 0;
+    if (p.exp_noise && p.noise_rows <= 0) return fail(VX_ERR_ARG, "noise_rows must be > 0");
+  }
+  VXC(sync_in(e, stream));
+  HIPC(hipMemcpyAsync(e->bst, e->h_bst, (size_t)B * sizeof(ArState), hipMemcpyHostToDevice, e->es));
+  const bool graph = !(c.flags & VX_FLAG_NO_GRAPH);
+  hipGraphExec_t gx = nullptr;
+  if (graph) {
+    auto it = e->bgraphs.find(B);
+    if (it == e->bgraphs.end()) {
+      hipGraph_t gr = nullptr;
+      HIPC(hipStreamBeginCapture(e->es, hipStreamCaptureModeThreadLocal));
+      int r = enqueue_batch_step(e, B, e->es);
+      hipError_t ce = hipStreamEndCapture(e->es, &gr);
+      if (r != VX_OK) return r;
+      HIPC(ce);
+      HIPC(hipGraphInstantiate(&gx, gr, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(gr);
+      e->bgraphs[B] = gx;
+    } else {
+      gx = it->second;
+    }
+  }
+  HIPC(hipEventRecord(e->ev_t[2], e->es));
+  long long launched = 0;
+  int slot = 0;
+  bool done = false, pending[2] = {false, false};
+  auto all_done = [&](int sl) {
+    const ArState* hs = e->h_bst + (size_t)(1 + sl) * BMAX;
+    for (int b = 0; b < B; ++b) if (!hs[b].done) return false;
+    return true;
+  };
+  while (!done) {
+    const long long n = (bound - launched) < POLL_CHUNK ? (bound - launched) : POLL_CHUNK;
+    for (long long i = 0; i < n; ++i) {
+      if (graph) HIPC(hipGraphLaunch(gx, e->es));
+      else VXC(enqueue_batch_step(e, B, e->es));
+    }
+    launched += n;
+    HIPC(hipMemcpyAsync(e->h_bst + (size_t)(1 + slot) * BMAX, e->bst, (size_t)B * sizeof(ArState), hipMemcpyDeviceToHost, e->es));
+    HIPC(hipEventRecord(e->ev_poll[slot], e->es));
+    pending[slot] = true;
+    const int other = slot ^ 1;
+    if (pending[other]) {
+      HIPC(hipEventSynchronize(e->ev_poll[other]));
+      pending[other] = false;
+      if (all_done(other)) done = true;
+    }
+    if (!done && launched >= bound) {
+      HIPC(hipEventSynchronize(e->ev_poll[slot]));
+      pending[slot] = false;
+      if (!all_done(slot)) return fail(VX_ERR_STATE, "batched decode did not terminate within %lld steps", bound);
+      done = true;
+    }
+    slot = other;
+  }
+  HIPC(hipEventRecord(e->ev_t[3], e->es));
+  HIPC(hipMemcpyAsync(e->h_bst + BMAX, e->bst, (size_t)B * sizeof(ArState), hipMemcpyDeviceToHost, e->es));
+  HIPC(hipStreamSynchronize(e->es));
+  HIPC(hipGetLastError());
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, e->ev_t[2], e->ev_t[3]));
+  e->t_bdecode = ms;
+  e->n_blaunch = (double)launched;
+  for (int b = 0; b < B; ++b) {
+    e->bngen[b] = e->h_bst[BMAX + b].n_gen;
+    e->breason[b] = e->h_bst[BMAX + b].stop_reason;
+    e->bprefilled[b] = false;
+  }
+  VXC(sync_out(e, stream));
+  return VX_OK;
+}
+
+extern "C" int vx_batch_result(vx_engine* e, int32_t slot, int64_t* tokens, int32_t capacity, int32_t* n_tokens,
+                               int32_t* stop_reason) {
+  if (!e) return fail(VX_ERR_ARG, "null engine");
+  if (slot < 0 || slot >= e->bmax) return fail(VX_ERR_ARG, "bad slot");
+  HIPC(hipSetDevice(e->cfg.device));
+  const int n = e->bngen[slot];
+  if (n_tokens) *n_tokens = n;
+  if (stop_reason) *stop_reason = e->breason[slot];
+  if (tokens) {
+    if (capacity < n) return fail(VX_ERR_CAPACITY, "token buffer too small (%d < %d)", capacity, n);
+    std::vector<int> tmp(n);
+    if (n) HIPC(hipMemcpy(tmp.data(), e->btok + (size_t)slot * e->btok_stride, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) tokens[i] = tmp[i];
+  }
+  return VX_OK;
+}
+
 // ------------------------------------------------------------------------------ NAR
 extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
                       const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream) {
@@ -790,8 +1036,8 @@ extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const i
 
 extern "C" int vx_get_timings(vx_engine* e, double* out, int32_t n) {
   if (!e || !out) return fail(VX_ERR_ARG, "null argument");
-  const double v[5] = {e->t_prefill, e->t_decode, e->t_nar, (double)e->n_pass, e->n_launch};
-  for (int i = 0; i < n && i < 5; ++i) out[i] = v[i];
+  const double v[7] = {e->t_prefill, e->t_decode, e->t_nar, (double)e->n_pass, e->n_launch, e->t_bdecode, e->n_blaunch};
+  for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
   return VX_OK;
 }
 
@@ -812,6 +1058,9 @@ extern "C" int vx_read_buffer(vx_engine* e, const char* name, void* dst, int64_t
   else if (n == "nar_logits") { src = (const char*)e->nar_logits; size = (int64_t)e->last_T * 1024 * 4; }
   else if (n == "ar_x") { src = (const char*)e->ar_x; size = (int64_t)e->cfg.d_model * 4; }
   else if (n == "nar_x") { src = (const char*)e->X; size = (int64_t)e->last_N * e->cfg.nar_d_model * 4; }
+  else if (n == "batch_logits" && e->bmax > 1) { src = (const char*)e->blogits; size = (int64_t)BMAX * LOGITS_CUR * 4; }
+  else if (n == "batch_argmax" && e->bmax > 1) { src = (const char*)e->bargm; size = (int64_t)BMAX * e->btok_stride * 4; }
+  else if (n == "batch_sampled" && e->bmax > 1) { src = (const char*)e->bsamp; size = (int64_t)BMAX * e->btok_stride * 4; }
   else return fail(VX_ERR_ARG, "unknown buffer '%s'", name);
   if (off < 0 || nbytes < 0 || off + nbytes > size) return fail(VX_ERR_ARG, "read of '%s' out of range (%lld+%lld > %lld)", name, (long long)off, (long long)nbytes, (long long)size);
   HIPC(hipMemcpy(dst, src + off, (size_t)nbytes, hipMemcpyDeviceToHost));

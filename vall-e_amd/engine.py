@@ -23,7 +23,7 @@ STOP_REASONS = {0: "none", 1: "eos_argmax", 2: "eos_sample", 3: "length", 4: "ma
 class VxConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "d_model", "nhead", "num_layers", "nar_d_model", "nar_nhead", "nar_num_layers",
-        "num_quantizers", "prefix_mode", "prepend_bos", "precision", "max_text", "max_audio", "device", "flags")]
+        "num_quantizers", "prefix_mode", "prepend_bos", "precision", "max_text", "max_audio", "device", "flags", "max_batch")]
 
 
 class VxDecodeParams(C.Structure):
@@ -53,6 +53,9 @@ _SIGS = {
     "vx_ar_decode": (C.c_int, [C.c_void_p, C.POINTER(VxDecodeParams), C.c_void_p]),
     "vx_ar_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vx_nar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "vx_batch_prefill": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "vx_batch_decode": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(VxDecodeParams), C.c_void_p]),
+    "vx_batch_result": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vx_get_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32]),
     "vx_read_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int64]),
     "vx_op_layernorm": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p]),
@@ -112,7 +115,7 @@ class Engine:
     """One model replica on one GPU (see include/vallex.h for the contract of each call)."""
 
     def __init__(self, cfg, precision: str = "bf16", max_text: int = 256, max_audio: int = 2048, device: int = 0,
-                 trace_logits: bool = False, no_graph: bool = False, simple_rows: bool = False):
+                 trace_logits: bool = False, no_graph: bool = False, simple_rows: bool = False, max_batch: int = 0):
         self.lib = load_library()
         self.cfg = cfg
         self.device = int(device)
@@ -126,7 +129,8 @@ class Engine:
         c.max_text, c.max_audio, c.device = max_text, max_audio, self.device
         c.flags = (VX_FLAG_TRACE_LOGITS if trace_logits else 0) | (VX_FLAG_NO_GRAPH if no_graph else 0) | \
                   (VX_FLAG_SIMPLE_ROWS if simple_rows else 0)
-        self.max_text, self.max_audio, self.trace_logits = max_text, max_audio, trace_logits
+        c.max_batch = int(max_batch)
+        self.max_text, self.max_audio, self.trace_logits, self.max_batch = max_text, max_audio, trace_logits, int(max_batch)
         h = C.c_void_p()
         _check(self.lib.vx_create(C.byref(c), C.byref(h)))
         self.h = h
@@ -203,10 +207,46 @@ class Engine:
                                _ptr(ar_tokens), T, _ptr(out), stream))
         return out
 
+    # -- batched decode (BASELINE configs[2]) -------------------------------------------------------
+    def batch_prefill(self, slot: int, text: torch.Tensor, prompt_cb0: torch.Tensor, stream=None):
+        text = text.to(torch.int64).contiguous()
+        prompt_cb0 = prompt_cb0.to(torch.int64).contiguous()
+        _check(self.lib.vx_batch_prefill(self.h, slot, _ptr(text), text.numel(), _ptr(prompt_cb0), prompt_cb0.numel(), stream))
+
+    def batch_decode(self, n_slots: int, top_k=-100, temperature=1.0, seeds=None, exp_noise=None, forced=None,
+                     max_new_tokens=-1, stream=None):
+        """exp_noise / forced: optional per-slot lists of DEVICE tensors (kept alive here for the call)."""
+        arr = (VxDecodeParams * n_slots)()
+        keep = []
+        for b in range(n_slots):
+            p = arr[b]
+            p.struct_size = C.sizeof(VxDecodeParams)
+            p.top_k, p.temperature, p.max_new_tokens = int(top_k), float(temperature), int(max_new_tokens)
+            p.seed = int(seeds[b]) if seeds is not None else b + 1
+            if exp_noise is not None and exp_noise[b] is not None:
+                t = exp_noise[b].to(torch.float32).contiguous()
+                assert t.is_cuda and t.shape[1] == 1025
+                p.exp_noise, p.noise_rows = _ptr(t), t.shape[0]
+                keep.append(t)
+            if forced is not None and forced[b] is not None:
+                t = forced[b].to(torch.int64).contiguous()
+                assert t.is_cuda
+                p.forced, p.n_forced = _ptr(t), t.numel()
+                keep.append(t)
+        _check(self.lib.vx_batch_decode(self.h, n_slots, arr, stream))
+
+    def batch_result(self, slot: int):
+        n, reason = C.c_int32(), C.c_int32()
+        _check(self.lib.vx_batch_result(self.h, slot, None, 0, C.byref(n), C.byref(reason)))
+        toks = torch.empty(n.value, dtype=torch.int64)
+        _check(self.lib.vx_batch_result(self.h, slot, _ptr(toks), n.value, C.byref(n), C.byref(reason)))
+        return toks, reason.value
+
     def timings(self):
-        buf = (C.c_double * 5)()
-        _check(self.lib.vx_get_timings(self.h, buf, 5))
-        return dict(prefill_ms=buf[0], decode_ms=buf[1], nar_ms=buf[2], n_pass=int(buf[3]), launches=int(buf[4]))
+        buf = (C.c_double * 7)()
+        _check(self.lib.vx_get_timings(self.h, buf, 7))
+        return dict(prefill_ms=buf[0], decode_ms=buf[1], nar_ms=buf[2], n_pass=int(buf[3]), launches=int(buf[4]),
+                    batch_decode_ms=buf[5], batch_launches=int(buf[6]))
 
     def read(self, name: str, shape, dtype=torch.float32, offset_bytes: int = 0) -> torch.Tensor:
         out = torch.empty(shape, dtype=dtype)

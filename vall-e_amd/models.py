@@ -31,7 +31,8 @@ class VALLE:
         self.engine_opts = dict(
             precision=kwargs.pop("precision", "bf16"), max_text=kwargs.pop("max_text", 512),
             max_audio=kwargs.pop("max_audio", 4096), trace_logits=kwargs.pop("trace_logits", False),
-            no_graph=kwargs.pop("no_graph", False), simple_rows=kwargs.pop("simple_rows", False))
+            no_graph=kwargs.pop("no_graph", False), simple_rows=kwargs.pop("simple_rows", False),
+            max_batch=kwargs.pop("max_batch", 0))
         self.sampling = kwargs.pop("sampling", "device")
         self.print_eos = kwargs.pop("print_eos", True)
         self.cfg = ModelConfig(decoder_dim=d_model, nhead=nhead, num_decoder_layers=num_layers, norm_first=norm_first,
@@ -165,6 +166,46 @@ class VALLE:
         codes = eng.nar(text_nar, prompts, tokens, out_device=self.device)
         return codes.unsqueeze(0)
 
+
+    @torch.no_grad()
+    def inference_batch(self, utterances, top_k: int = -100, temperature: float = 1.0, seeds=None):
+        """Engine extension (BASELINE configs[2]): ``utterances`` = list of (x, x_lens, y[, enroll_x_lens]) as for
+        ``inference``; up to ``max_batch`` of them advance together, one shared weight stream per AR step, each with
+        its own KV cache / sampler / stop rule; the NAR stages then run per utterance.  Returns a list of (1,T_i,Q)."""
+        eng = self.engine()
+        if eng.max_batch < 2:
+            raise RuntimeError("construct the model with max_batch >= 2 for inference_batch")
+        Q, bos = self.num_quantizers, int(self.ar_audio_prepend_bos)
+        out = [None] * len(utterances)
+        for g0 in range(0, len(utterances), eng.max_batch):
+            group = utterances[g0 : g0 + eng.max_batch]
+            for b, u in enumerate(group):
+                x, x_lens, y = u[0], u[1], u[2]
+                assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3 and y.shape[0] == 1 and torch.all(x_lens > 0)
+                if x.shape[1] != int(x_lens.max()) or x.shape[0] != 1:
+                    raise RuntimeError("x must be one unpadded sequence per utterance")
+                if int(x.min()) < 0 or int(x.max()) >= NUM_TEXT_TOKENS or int(y.min()) < 0 or int(y[..., :Q].max()) >= NUM_AUDIO_TOKENS:
+                    raise IndexError("index out of range in self")
+                eng.batch_prefill(b, x[0], y[0, :, 0].contiguous())
+            sd = [int(torch.randint(0, 2**62, (1,))) for _ in group] if seeds is None else list(seeds[g0 : g0 + len(group)])
+            eng.batch_decode(len(group), top_k=top_k, temperature=temperature, seeds=sd)
+            for b, u in enumerate(group):
+                x, x_lens, y = u[0], u[1], u[2]
+                enroll = u[3] if len(u) > 3 else None
+                tokens, reason = eng.batch_result(b)
+                if tokens.numel() == 0 and not bos:
+                    raise SyntaxError("well trained model shouldn't reach here.")
+                if Q == 1 or tokens.numel() == 0:
+                    codes = torch.zeros((tokens.numel(), Q), dtype=torch.int64)
+                    codes[:, 0] = tokens
+                    out[g0 + b] = codes.unsqueeze(0).to(self.device)
+                    continue
+                text_nar = x[0]
+                if self.prefix_mode in [2, 4]:
+                    enrolled_len = int(enroll.max().item())
+                    text_nar = torch.concat([x[0][:1], x[0][enrolled_len - 1:]])
+                out[g0 + b] = eng.nar(text_nar, y[0, :, :Q].contiguous(), tokens, out_device=self.device).unsqueeze(0)
+        return out
 
     @torch.no_grad()
     def continual(self, x: torch.Tensor, x_lens: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
