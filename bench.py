@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=1, help="utterances decoded together per GPU per step (1 = the headline "
+                    "batch-1 workload, BASELINE configs[1]; 32 = configs[2]/[3])")
     ap.add_argument("--no-graph", action="store_true", help="launch the AR step kernel by kernel (rocprofv3 --pmc cannot follow hipGraph replays)")
     args = ap.parse_args()
 
@@ -101,7 +103,7 @@ def main():
     cfg = ModelConfig(decoder_dim=1024, nhead=16, num_decoder_layers=12, prefix_mode=1)
     sd = synthetic_state_dict(cfg, seed=0)
     model = VALLE(1024, 16, 12, prefix_mode=1, precision=args.precision, max_text=64, max_audio=1024, print_eos=False,
-                  no_graph=args.no_graph)
+                  no_graph=args.no_graph, max_batch=args.batch if args.batch > 1 else 0)
     model.load_state_dict(sd)
     model.to(dev).eval()
     eng = model.engine()
@@ -110,18 +112,27 @@ def main():
     # rank 0 owns every utterance of the job: (world * n_total) independent inputs
     utts = None
     if rank == 0:
-        utts = [synthetic_inputs(S_TEXT, P_PROMPT, 8, seed=1 + i) for i in range(world * n_total)]
+        utts = [synthetic_inputs(S_TEXT, P_PROMPT, 8, seed=1 + i) for i in range(world * n_total * args.batch)]
 
     def run_phase(step_ids):
         """scatter -> decode -> gather for the utterances of these steps; returns #frames produced here."""
-        mine = scatter_utterances([utts[s * world + r] for s in step_ids for r in range(world)] if rank == 0 else None,
-                                  len(step_ids), dev, world, rank)
+        Bt = args.batch
+        mine = scatter_utterances([utts[(s * world + r) * Bt + j] for s in step_ids for j in range(Bt) for r in range(world)]
+                                  if rank == 0 else None, len(step_ids) * Bt, dev, world, rank)
         outs, frames = [], 0
-        for i, (x, x_lens, y) in enumerate(mine):
-            torch.manual_seed(1234 + step_ids[i] * world + rank)  # seeds the on-device sampler
-            codes = model.inference(x, x_lens, y, None, top_k=TOP_K, temperature=TEMP)
-            outs.append(codes)
-            frames += codes.shape[1]
+        if Bt > 1:
+            for i in range(len(step_ids)):
+                group = mine[i * Bt : (i + 1) * Bt]
+                res = model.inference_batch(group, top_k=TOP_K, temperature=TEMP,
+                                            seeds=[1234 + (step_ids[i] * world + rank) * Bt + j for j in range(Bt)])
+                outs += res
+                frames += sum(c.shape[1] for c in res)
+        else:
+            for i, (x, x_lens, y) in enumerate(mine):
+                torch.manual_seed(1234 + step_ids[i] * world + rank)  # seeds the on-device sampler
+                codes = model.inference(x, x_lens, y, None, top_k=TOP_K, temperature=TEMP)
+                outs.append(codes)
+                frames += codes.shape[1]
         gather_codes(outs, dev, world, rank)
         return frames, outs
 
@@ -150,26 +161,37 @@ def main():
         T = outs[-1].shape[1]
         ctx_mean = S_TEXT + P_PROMPT + (T - 1) / 2.0
         bpe = 2 if args.precision == "bf16" else 4
-        step_s = tm["decode_ms"] * 1e-3 / max(1, tm["launches"])
-        achieved = ar_bytes_per_token(1024, 12, ctx_mean, bpe) / step_s / 1e9
+        Bt = args.batch
+        if Bt > 1:  # batched step: weights once + Bt KV streams
+            step_s = tm["batch_decode_ms"] * 1e-3 / max(1, tm["batch_launches"])
+            step_bytes = ar_bytes_per_token(1024, 12, 0, bpe) + Bt * 2 * 12 * 1024 * bpe * ctx_mean
+            tm = dict(tm, decode_ms=tm["batch_decode_ms"], launches=tm["batch_launches"] * Bt)
+        else:
+            step_s = tm["decode_ms"] * 1e-3 / max(1, tm["launches"])
+            step_bytes = ar_bytes_per_token(1024, 12, ctx_mean, bpe)
+        achieved = step_bytes / step_s / 1e9
         out = {
             "metric": "AR codec-tokens/sec/GPU + NAR 7-stage p50 latency, d=1024 L=12 10s utterance",
             "value": round(frames / dt, 2), "unit": "codec-tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: d=1024 nhead=16 L=12, batch=1 AR top-k(10) + 7 NAR stages, "
-                                   f"S={S_TEXT} P={P_PROMPT} -> T={T} frames x 8 codebooks, one utterance per GPU per step",
+            "config": {"workload": (f"BASELINE configs[1]: d=1024 nhead=16 L=12, batch=1 AR top-k(10) + 7 NAR stages, "
+                                    f"S={S_TEXT} P={P_PROMPT} -> T={T} frames x 8 codebooks, one utterance per GPU per step")
+                       if Bt == 1 else
+                       (f"BASELINE configs[2]: d=1024 nhead=16 L=12, batch={Bt} concurrent utterances per GPU (padded KV, "
+                        f"hipGraph step) + per-utterance NAR, S={S_TEXT} P={P_PROMPT} -> T={T} x 8"),
                        "parallelism": f"replica x{world} (utterance sharding, RCCL scatter/gather)"},
             "ar_tokens_per_s": round(tm["launches"] / (tm["decode_ms"] * 1e-3), 1),
             "ar_step_us": round(step_s * 1e6, 2),
             "prefill_ms": round(tm["prefill_ms"], 3),
             "nar_7stage_ms": round(tm["nar_ms"], 3),
-            "roofline": {"bound": "hbm", "kernel": "AR decode step (hipGraph of 62 kernels = 1 token)",
+            "roofline": {"bound": "hbm", "kernel": "AR decode step (hipGraph of 62 kernels = 1 token)" if Bt == 1 else
+                         f"batched AR decode step (hipGraph of 87 kernels = {Bt} tokens)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(ctx_mean) if args.precision == "bf16" else None,
-                         "bytes_per_launch": int(ar_bytes_per_token(1024, 12, ctx_mean, bpe))},
+                         "traffic": measured_traffic(ctx_mean) if (args.precision == "bf16" and Bt == 1) else None,
+                         "bytes_per_launch": int(step_bytes)},
         }
         if world == 1 and not args.no_cpu_baseline:
             x, x_lens, y = utts[0]

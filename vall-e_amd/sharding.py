@@ -88,7 +88,11 @@ def gather_codes(codes: Sequence[torch.Tensor], device, world: int, rank: int) -
     return out
 
 
-def infer_sharded(run_one, all_utts: Optional[Sequence[Utt]], per_rank: int, device, world: int, rank: int):
-    """scatter -> ``run_one(x, x_lens, y) -> (1,T,Q) codes`` per local utterance -> gather."""
+def infer_sharded(run_one, all_utts: Optional[Sequence[Utt]], per_rank: int, device, world: int, rank: int,
+                  run_many=None):
+    """scatter -> decode the local utterances -> gather.  ``run_one(x, x_lens, y) -> (1,T,Q)`` decodes them one
+    at a time (batch-1, the reference's mode); ``run_many(list_of_utts) -> list of (1,T,Q)`` decodes them as one
+    padded batch (``VALLE.inference_batch``, BASELINE configs[3]: 256 utterances = 32 per GPU on 8 GPUs)."""
     mine = scatter_utterances(all_utts, per_rank, device, world, rank)
-    return gather_codes([run_one(*u) for u in mine], device, world, rank)
+    outs = run_many(mine) if run_many is not None else [run_one(*u) for u in mine]
+    return gather_codes(outs, device, world, rank)
