@@ -142,6 +142,12 @@ int vx_batch_decode(vx_engine* e, int32_t n_slots, const vx_decode_params* param
 int vx_batch_result(vx_engine* e, int32_t slot, int64_t* tokens, int32_t capacity, int32_t* n_tokens,
                     int32_t* stop_reason);
 
+/* The NAR stages of n (<= 32) utterances in one pass: rows are concatenated so the GEMMs run at M ~ n x 1k.
+ * Arguments are arrays of n pointers / sizes with the meaning of vx_nar's. */
+int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_nar, const int32_t* S2,
+                 const int64_t* const* prompts, const int32_t* P, const int64_t* const* ar_tokens, const int32_t* T,
+                 int64_t* const* codes_out, void* stream);
+
 /* Device-time of the last calls, measured with HIP events on the engine's stream:
  * out[0] prefill ms, out[1] AR decode ms, out[2] NAR ms, out[3] AR passes, out[4] graph launches. */
 int vx_get_timings(vx_engine* e, double* out, int32_t n);

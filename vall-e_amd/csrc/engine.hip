@@ -106,6 +106,8 @@ struct vx_engine {
   int *btok = nullptr, *bsamp = nullptr, *bargm = nullptr;
   int btok_stride = 0;
   std::unordered_map<int, hipGraphExec_t> bgraphs;
+  int *d_seg_start = nullptr, *d_seg_len = nullptr;  // batched NAR segments
+  int nseg = 0, max_seg_len = 0;
   int bS[BMAX] = {}, bP[BMAX] = {}, bbos[BMAX] = {}, bngen[BMAX] = {}, breason[BMAX] = {};
   bool bprefilled[BMAX] = {};
   double t_bdecode = 0, n_blaunch = 0;
@@ -496,6 +498,9 @@ static int ln_rows(vx_engine* e, const float* x, const float* g, const float* b,
 
 static int attn_rows(vx_engine* e, const void* qkv, void* out, int M, int d, int H, int text_len) {
   const float scale = 1.0f / sqrtf(64.0f);
+  if (e->nseg > 0)  // batched NAR: one launch over all segments of the concatenated rows
+    return mfma_attn_dispatch((const bf16*)qkv, (const bf16*)e->VT, e->vt_ld, (bf16*)out, M, d, H, text_len, e->es,
+                              e->d_seg_start, e->d_seg_len, e->nseg, e->max_seg_len);
   if (use_mfma(e)) return mfma_attn_dispatch((const bf16*)qkv, (const bf16*)e->VT, e->vt_ld, (bf16*)out, M, d, H, text_len, e->es);
   dim3 grid((M + 63) / 64, H);
   if (e->bf16) attn_rows_simple_kernel<bf16, 64><<<grid, 256, 0, e->es>>>((const bf16*)qkv, (bf16*)out, M, d, text_len, scale);
@@ -1030,6 +1035,136 @@ extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const i
   HIPC(hipEventElapsedTime(&ms, e->ev_t[4], e->ev_t[5]));
   e->t_nar = ms;
   e->last_T = T; e->last_N = N;
+  VXC(sync_out(e, stream));
+  return VX_OK;
+}
+
+// Row buffers are sized for one utterance at vx_create; the batched NAR concatenates up to max_batch of them.
+static int ensure_rows(vx_engine* e, size_t rows, size_t audio_rows, size_t text_rows) {
+  const vx_config& c = e->cfg;
+  const size_t dmax = c.d_model > c.nar_d_model ? c.d_model : c.nar_d_model;
+  if (rows <= (size_t)e->n_max) return VX_OK;
+  HIPC(hipStreamSynchronize(e->es));
+  auto regrow = [&](void** p, size_t bytes) -> int {
+    for (auto& q : e->allocs) if (q == *p) { (void)hipFree(q); q = nullptr; }
+    HIPC(hipMalloc(p, bytes));
+    e->allocs.push_back(*p);
+    return VX_OK;
+  };
+  e->n_max = (int)rows;
+  e->vt_ld = (int)(((rows + 63) / 64) * 64 + 64);
+  VXC(regrow((void**)&e->X, rows * dmax * 4));
+  VXC(regrow(&e->Hn, rows * dmax * e->esz));
+  VXC(regrow(&e->QKV, rows * 3 * dmax * e->esz));
+  VXC(regrow(&e->ATT, rows * dmax * e->esz));
+  HIPC(hipMemset(e->ATT, 0, rows * dmax * e->esz));  // padding rows between segments are never written: keep them finite
+  VXC(regrow(&e->FF, rows * 4 * dmax * e->esz));
+  VXC(regrow(&e->VT, dmax * (size_t)e->vt_ld * 2));
+  HIPC(hipMemset(e->VT, 0, dmax * (size_t)e->vt_ld * 2));
+  HIPC(hipMemset(e->X, 0, rows * dmax * 4));
+  VXC(regrow((void**)&e->yemb, audio_rows * dmax * 4));
+  VXC(regrow((void**)&e->nar_logits, audio_rows * 1024 * 4));
+  VXC(regrow((void**)&e->ids_text, text_rows * 8));
+  VXC(regrow((void**)&e->ids_prompts, audio_rows * 8 * 8));
+  VXC(regrow((void**)&e->ids_samples, audio_rows * 8));
+  VXC(regrow((void**)&e->d_codes, audio_rows * 8 * 8));
+  return VX_OK;
+}
+
+// The NAR stages of n utterances at once (valle.py:1063-1134 per utterance): rows of all utterances are
+// concatenated (each segment starts at a multiple of 64 rows), so the GEMMs run at M ~ n x 1k rows where the
+// MFMA kernels are efficient, and attention runs per segment in one launch.
+extern "C" int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_nar, const int32_t* S2,
+                            const int64_t* const* prompts, const int32_t* P, const int64_t* const* ar_tokens,
+                            const int32_t* T, int64_t* const* codes_out, void* stream) {
+  if (!e || !text_nar || !S2 || !prompts || !P || !ar_tokens || !T || !codes_out) return fail(VX_ERR_ARG, "null argument");
+  if (!e->finalized) return fail(VX_ERR_STATE, "weights not finalized");
+  const vx_config& c = e->cfg;
+  const int Q = c.num_quantizers, dn = c.nar_d_model;
+  if (n < 1 || n > BMAX) return fail(VX_ERR_ARG, "n must be 1..%d", BMAX);
+  if (!e->bf16 || !use_mfma(e) || Q < 2) return fail(VX_ERR_UNSUPPORTED, "vx_nar_batch needs bf16 MFMA rows and num_quantizers > 1");
+  HIPC(hipSetDevice(c.device));
+  std::vector<int> start(n), len(n), aoff(n), toff(n), soff(n);
+  size_t rows = 0, arows = 0, trows = 0, srows = 0;
+  int maxlen = 0;
+  for (int b = 0; b < n; ++b) {
+    if (S2[b] <= 0 || T[b] <= 0 || P[b] < 0 || !text_nar[b] || !ar_tokens[b] || !codes_out[b] || (P[b] > 0 && !prompts[b]))
+      return fail(VX_ERR_ARG, "bad utterance %d", b);
+    start[b] = (int)rows; len[b] = S2[b] + P[b] + T[b];
+    aoff[b] = (int)arows; toff[b] = (int)trows; soff[b] = (int)srows;
+    rows += (size_t)((len[b] + 63) / 64) * 64;
+    arows += P[b] + T[b]; trows += T[b]; srows += S2[b];
+    if (len[b] > maxlen) maxlen = len[b];
+  }
+  VXC(ensure_rows(e, rows, arows, srows));
+  VXC(sync_in(e, stream));
+  HIPC(hipEventRecord(e->ev_t[4], e->es));
+  if (!e->d_seg_start) {
+    HIPC(hipMalloc((void**)&e->d_seg_start, BMAX * sizeof(int)));
+    HIPC(hipMalloc((void**)&e->d_seg_len, BMAX * sizeof(int)));
+    e->allocs.push_back(e->d_seg_start); e->allocs.push_back(e->d_seg_len);
+  }
+  HIPC(hipMemcpyAsync(e->d_seg_start, start.data(), n * sizeof(int), hipMemcpyHostToDevice, e->es));
+  HIPC(hipMemcpyAsync(e->d_seg_len, len.data(), n * sizeof(int), hipMemcpyHostToDevice, e->es));
+  HIPC(hipMemsetAsync(e->X, 0, rows * (size_t)dn * 4, e->es));  // padding rows must stay finite (they feed V^T columns)
+  auto emb = [&](int j) { return W<float>(e, "nar_audio_embeddings." + std::to_string(j) + ".word_embeddings.weight"); };
+  for (int b = 0; b < n; ++b) {
+    long long* idp = e->ids_prompts + (size_t)aoff[b] * Q;   // (P_b, Q) rows; region sized for P+T rows per utterance
+    long long* ids = e->ids_samples + toff[b];
+    if (P[b]) HIPC(hipMemcpyAsync(idp, prompts[b], (size_t)P[b] * Q * 8, hipMemcpyDefault, e->es));
+    HIPC(hipMemcpyAsync(ids, ar_tokens[b], (size_t)T[b] * 8, hipMemcpyDefault, e->es));
+    HIPC(hipMemcpyAsync(e->ids_text + soff[b], text_nar[b], (size_t)S2[b] * 8, hipMemcpyDefault, e->es));
+    copy_col_kernel<<<(T[b] + 255) / 256, 256, 0, e->es>>>(ids, e->d_codes + (size_t)toff[b] * Q, T[b], Q, 0);
+    float* ye = e->yemb + (size_t)aoff[b] * dn;
+    if (P[b]) embed_accum_kernel<<<P[b], 256, 0, e->es>>>(idp, Q, 0, emb(0), 1025, dn, ye, P[b], 1);
+    embed_accum_kernel<<<T[b], 256, 0, e->es>>>(ids, 1, 0, emb(0), 1025, dn, ye + (size_t)P[b] * dn, T[b], 1);
+    if (c.prefix_mode != 0 && P[b])
+      for (int j = 1; j < Q; ++j) embed_accum_kernel<<<P[b], 256, 0, e->es>>>(idp, Q, j, emb(j), 1024, dn, ye, P[b], 0);
+  }
+  const float* a_txt = W<float>(e, "nar_text_position.alpha");
+  const float* a_aud = W<float>(e, "nar_audio_position.alpha");
+  e->nseg = n; e->max_seg_len = maxlen;
+  int rc = VX_OK;
+  for (int i = 0; i < Q - 1 && rc == VX_OK; ++i) {
+    for (int b = 0; b < n; ++b) {
+      float* xb = e->X + (size_t)start[b] * dn;
+      embed_pos_kernel<<<S2[b], 256, 0, e->es>>>(e->ids_text + soff[b], 1, 0, W<float>(e, "nar_text_embedding.word_embeddings.weight"),
+                                                 512, dn, a_txt, e->pe_nar, 0, xb, S2[b]);
+      add_pos_kernel<<<P[b] + T[b], 256, 0, e->es>>>(e->yemb + (size_t)aoff[b] * dn, dn, a_aud, e->pe_nar, 0,
+                                                     xb + (size_t)S2[b] * dn, P[b] + T[b]);
+    }
+    rc = run_stack(e, e->nar_l, (int)rows, dn, c.nar_nhead, -1, i, false);
+    if (rc != VX_OK) break;
+    const float* fw = ada_vec(e, i, 2 * c.nar_num_layers);
+    for (int b = 0; b < n; ++b)  // final AdaLN on the generated rows only, compacted to [sum T][dn]
+      rc = ln_rows(e, e->X + (size_t)(start[b] + S2[b] + P[b]) * dn, W<float>(e, "nar_decoder.norm.norm.weight"),
+                   W<float>(e, "nar_decoder.norm.norm.bias"), fw, fw + dn, (bf16*)e->Hn + (size_t)toff[b] * dn, T[b], dn);
+    const int nseg_keep = e->nseg;
+    e->nseg = 0;  // the predict GEMM below is a plain GEMM
+    rc = gemm_rows(e, e->Hn, W<void>(e, "nar_predict_layers." + std::to_string(i) + ".weight"), nullptr, e->nar_logits,
+                   (int)trows, 1024, dn, GE_PLAIN, true);
+    e->nseg = nseg_keep;
+    if (rc != VX_OK) break;
+    argmax_rows_kernel<<<((int)trows + 3) / 4, 256, 0, e->es>>>(e->nar_logits, 1024, (int)trows, e->ids_samples, e->d_codes, Q, i + 1);
+    if (i < Q - 2)
+      for (int b = 0; b < n; ++b) {
+        float* ye = e->yemb + (size_t)aoff[b] * dn;
+        if (c.prefix_mode == 0 && P[b])
+          embed_accum_kernel<<<P[b], 256, 0, e->es>>>(e->ids_prompts + (size_t)aoff[b] * Q, Q, i + 1, emb(i + 1), 1024, dn, ye, P[b], 0);
+        embed_accum_kernel<<<T[b], 256, 0, e->es>>>(e->ids_samples + toff[b], 1, 0, emb(i + 1), 1024, dn, ye + (size_t)P[b] * dn, T[b], 0);
+      }
+  }
+  e->nseg = 0;
+  VXC(rc);
+  HIPC(hipGetLastError());
+  HIPC(hipEventRecord(e->ev_t[5], e->es));
+  for (int b = 0; b < n; ++b)
+    HIPC(hipMemcpyAsync(codes_out[b], e->d_codes + (size_t)toff[b] * Q, (size_t)T[b] * Q * 8, hipMemcpyDefault, e->es));
+  HIPC(hipStreamSynchronize(e->es));
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, e->ev_t[4], e->ev_t[5]));
+  e->t_nar = ms;
+  e->last_T = (int)trows; e->last_N = (int)rows;
   VXC(sync_out(e, stream));
   return VX_OK;
 }

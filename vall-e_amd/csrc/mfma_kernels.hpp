@@ -374,8 +374,19 @@ __device__ __forceinline__ float xor32_f(float v) {
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void mfma_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
                                                             bf16* __restrict__ out, int M, int vt_ld, int d,
-                                                            int text_len) {
+                                                            int text_len, const int* __restrict__ seg_start,
+                                                            const int* __restrict__ seg_len) {
   constexpr int HD = 64, NT = NW * 64;
+  // batched NAR: segment z of a concatenated row buffer (starts are multiples of 64 rows, so the 16-byte K / V^T
+  // tile loads stay aligned); single sequence: seg_start == nullptr
+  if (seg_start != nullptr) {
+    const int r0 = seg_start[blockIdx.z];
+    M = seg_len[blockIdx.z];
+    if ((int)blockIdx.x * 32 * NW >= M) return;
+    qkv += (size_t)r0 * 3 * d;
+    out += (size_t)r0 * d;
+    vt += r0;
+  }
   constexpr int CPT = 512 / NT;  // 16-byte chunks per thread per operand tile (64 rows x 8 chunks)
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][64 * 128];  // [buf][K | V^T][row * 128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -528,10 +539,12 @@ __global__ __launch_bounds__(256) void vt_from_qkv_kernel(const bf16* __restrict
 }
 
 static inline int mfma_attn_dispatch(const bf16* qkv, const bf16* vt, int vt_ld, bf16* out, int M, int d, int H,
-                                     int text_len, hipStream_t s) {
+                                     int text_len, hipStream_t s, const int* seg_start = nullptr,
+                                     const int* seg_len = nullptr, int nseg = 1, int max_seg_len = 0) {
   constexpr int NW = 2;
-  dim3 grid((M + 32 * NW - 1) / (32 * NW), H);
-  mfma_attn_kernel<NW><<<grid, NW * 64, 0, s>>>(qkv, vt, out, M, vt_ld, d, text_len);
+  const int rows = seg_start ? max_seg_len : M;
+  dim3 grid((rows + 32 * NW - 1) / (32 * NW), H, seg_start ? nseg : 1);
+  mfma_attn_kernel<NW><<<grid, NW * 64, 0, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len);
   return 0;
 }
 

@@ -56,6 +56,7 @@ _SIGS = {
     "vx_batch_prefill": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "vx_batch_decode": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(VxDecodeParams), C.c_void_p]),
     "vx_batch_result": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "vx_nar_batch": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 7 + [C.c_void_p]),
     "vx_get_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32]),
     "vx_read_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int64]),
     "vx_op_layernorm": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p]),
@@ -241,6 +242,21 @@ class Engine:
         toks = torch.empty(n.value, dtype=torch.int64)
         _check(self.lib.vx_batch_result(self.h, slot, _ptr(toks), n.value, C.byref(n), C.byref(reason)))
         return toks, reason.value
+
+    def nar_batch(self, texts, prompts, tokens, out_device=None, stream=None):
+        """lists of per-utterance tensors (as for ``nar``) -> list of (T_i, Q) int64 code tensors."""
+        n, Q = len(texts), self.cfg.num_quantizers
+        texts = [t.to(torch.int64).contiguous() for t in texts]
+        prompts = [p.to(torch.int64).contiguous() for p in prompts]
+        tokens = [t.to(torch.int64).contiguous() for t in tokens]
+        outs = [torch.empty((t.numel(), Q), dtype=torch.int64, device=out_device if out_device is not None else p.device)
+                for t, p in zip(tokens, prompts)]
+        ptrs = lambda ts: (C.c_void_p * n)(*[_ptr(t) for t in ts])
+        ints = lambda vs: (C.c_int32 * n)(*vs)
+        _check(self.lib.vx_nar_batch(self.h, n, ptrs(texts), ints([t.numel() for t in texts]), ptrs(prompts),
+                                     ints([p.shape[0] for p in prompts]), ptrs(tokens), ints([t.numel() for t in tokens]),
+                                     ptrs(outs), stream))
+        return outs
 
     def timings(self):
         buf = (C.c_double * 7)()

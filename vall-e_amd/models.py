@@ -168,7 +168,7 @@ class VALLE:
 
 
     @torch.no_grad()
-    def inference_batch(self, utterances, top_k: int = -100, temperature: float = 1.0, seeds=None):
+    def inference_batch(self, utterances, top_k: int = -100, temperature: float = 1.0, seeds=None, batched_nar: bool = True):
         """Engine extension (BASELINE configs[2]): ``utterances`` = list of (x, x_lens, y[, enroll_x_lens]) as for
         ``inference``; up to ``max_batch`` of them advance together, one shared weight stream per AR step, each with
         its own KV cache / sampler / stop rule; the NAR stages then run per utterance.  Returns a list of (1,T_i,Q)."""
@@ -189,6 +189,7 @@ class VALLE:
                 eng.batch_prefill(b, x[0], y[0, :, 0].contiguous())
             sd = [int(torch.randint(0, 2**62, (1,))) for _ in group] if seeds is None else list(seeds[g0 : g0 + len(group)])
             eng.batch_decode(len(group), top_k=top_k, temperature=temperature, seeds=sd)
+            todo = []  # (index, text_nar, prompts, tokens) of the utterances that go through the NAR stages
             for b, u in enumerate(group):
                 x, x_lens, y = u[0], u[1], u[2]
                 enroll = u[3] if len(u) > 3 else None
@@ -204,7 +205,14 @@ class VALLE:
                 if self.prefix_mode in [2, 4]:
                     enrolled_len = int(enroll.max().item())
                     text_nar = torch.concat([x[0][:1], x[0][enrolled_len - 1:]])
-                out[g0 + b] = eng.nar(text_nar, y[0, :, :Q].contiguous(), tokens, out_device=self.device).unsqueeze(0)
+                todo.append((g0 + b, text_nar, y[0, :, :Q].contiguous(), tokens))
+            if todo and batched_nar:
+                res = eng.nar_batch([t[1] for t in todo], [t[2] for t in todo], [t[3] for t in todo], out_device=self.device)
+                for (i, *_), r in zip(todo, res):
+                    out[i] = r.unsqueeze(0)
+            else:
+                for i, tn, pr, tk in todo:
+                    out[i] = eng.nar(tn, pr, tk, out_device=self.device).unsqueeze(0)
         return out
 
     @torch.no_grad()
