@@ -128,3 +128,17 @@ def test_sampling_matches_oracle_bit_exact(eng, top_k, temp):
         got, am = eng.op_sample(logits[0].cuda(), top_k, temp, q[0].cuda())
         assert am == int(torch.argmax(logits, -1))
         assert got == want, (seed, top_k, temp)
+
+
+@pytest.mark.parametrize("top_k", [-1, 7, 80])
+def test_sampling_single_wave_variant_large_vocab(eng, top_k):
+    """V = 1500 > 1088 routes vx_op_sample to the single-wave kernel (32 keys per lane): same exactness."""
+    from oracle import valle_oracle as vo
+
+    for seed in range(6):
+        logits = _rand(1, 1500, seed=50 + seed, scale=2.5)
+        g = torch.Generator().manual_seed(500 + seed)
+        q = torch.empty(1, 1500).exponential_(1, generator=g)
+        want = int(vo.topk_sampling(logits.clone(), top_k, 0.9, q))
+        got, am = eng.op_sample(logits[0].cuda(), top_k, 0.9, q[0].cuda())
+        assert am == int(torch.argmax(logits, -1)) and got == want

@@ -386,6 +386,55 @@ __device__ __forceinline__ uint32_t kth_largest_1reg(uint32_t x, int k) {
   return T;
 }
 
+// Exact k-th largest of the NV*64 keys one wave holds (NV per lane, 0 = absent): the top-k threshold of
+// valle.py:1254-1260 on order-preserving keys.  Counts are ballots (scalar), so every branch is wave-uniform.
+// For k <= 64 the search is first narrowed: the k-th largest of the 64 per-lane maxima is a lower bound L of the
+// answer, so only keys >= L (usually k..k+3 of them) can matter; they are compacted into one register through
+// LDS (same wave writes and reads: the LDS queue is in order, no barrier) and selected there.
+template <int NV>
+__device__ __forceinline__ uint32_t topk_threshold_wave(const uint32_t (&key)[NV], int top_k, int lane, uint32_t* cand_lds) {
+  if (top_k <= 64) {
+    uint32_t lm = key[0];
+#pragma unroll
+    for (int j = 1; j < NV; ++j) lm = max(lm, key[j]);
+    const uint32_t L = kth_largest_1reg(lm, top_k);
+    int cL = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) cL += __popcll(__ballot(key[j] >= L));
+    if (cL == top_k) return L;
+    if (cL <= 64) {
+      int base = 0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const unsigned long long mk = __ballot(key[j] >= L);
+        const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+        if (key[j] >= L) cand_lds[pos] = key[j];
+        base += __popcll(mk);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      const uint32_t c = (lane < cL) ? cand_lds[lane] : 0u;
+      return kth_largest_1reg(c, top_k);
+    }
+  }
+  uint32_t T = 0u;
+  for (int b = 31; b >= 0; --b) {
+    const uint32_t cand = T | (1u << b);
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) c += __popcll(__ballot(key[j] >= cand));
+    if (c >= top_k) {
+      T = cand;
+      if (c == top_k) {  // the kept set is exactly {key >= cand}: its minimum is the k-th largest
+        uint32_t mn = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) mn = (key[j] >= cand) ? min(mn, key[j]) : mn;
+        return wave_umin_dpp(mn);
+      }
+    }
+  }
+  return T;
+}
+
 // ONE wave: lane l owns logits l, l+64, ..., l+64*(NV-1) in registers.  Everything the stop rule
 // depends on is a wave-level DPP reduction or a ballot — no LDS, no barrier on the token's critical path.
 template <int NV>
@@ -440,51 +489,7 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
     uint32_t key[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) key[j] = (j * 64 + lane < V) ? order_key(v[j]) : 0u;
-    bool found = false;
-    if (top_k <= 64) {
-      uint32_t lm = key[0];
-#pragma unroll
-      for (int j = 1; j < NV; ++j) lm = max(lm, key[j]);
-      const uint32_t L = kth_largest_1reg(lm, top_k);
-      int cL = 0;
-#pragma unroll
-      for (int j = 0; j < NV; ++j) cL += __popcll(__ballot(key[j] >= L));
-      if (cL == top_k) {
-        T = L;
-        found = true;
-      } else if (cL <= 64) {
-        int base = 0;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          const unsigned long long mk = __ballot(key[j] >= L);
-          const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-          if (key[j] >= L) cand_lds[pos] = key[j];
-          base += __popcll(mk);
-        }
-        __syncthreads();  // one wave: orders the LDS writes before the reads
-        const uint32_t c = (lane < cL) ? cand_lds[lane] : 0u;
-        T = kth_largest_1reg(c, top_k);
-        found = true;
-      }
-    }
-    if (!found) {
-      for (int b = 31; b >= 0; --b) {
-        const uint32_t cand = T | (1u << b);
-        int c = 0;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) c += __popcll(__ballot(key[j] >= cand));
-        if (c >= top_k) {
-          T = cand;
-          if (c == top_k) {  // the kept set is exactly {key >= cand}: its minimum is the k-th largest
-            uint32_t mn = 0xffffffffu;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) mn = (key[j] >= cand) ? min(mn, key[j]) : mn;
-            T = wave_umin_dpp(mn);
-            break;
-          }
-        }
-      }
-    }
+    T = topk_threshold_wave<NV>(key, top_k, lane, cand_lds);
   }
   bool keep[NV];
 #pragma unroll
@@ -549,6 +554,147 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
   // x = E[tok] * 1.0 + alpha * pe[audio position] (valle.py:1013-1015; embedding.py:93-97)
   const int apos = row - S;
   for (int c = lane * 4; c < a.d; c += 256) {
+    const float4 ev = *reinterpret_cast<const float4*>(a.emb + (size_t)tok * a.d + c);
+    const float4 pv = *reinterpret_cast<const float4*>(a.pe + (size_t)apos * a.d + c);
+    float4 o;
+    o.x = __fadd_rn(ev.x, __fmul_rn(alpha, pv.x)); o.y = __fadd_rn(ev.y, __fmul_rn(alpha, pv.y));
+    o.z = __fadd_rn(ev.z, __fmul_rn(alpha, pv.z)); o.w = __fadd_rn(ev.w, __fmul_rn(alpha, pv.w));
+    *reinterpret_cast<float4*>(xout + c) = o;
+  }
+}
+
+// Four-wave variant used by the decode step: the single-wave kernel above executes ~3000 instructions
+// serially; here thread t owns logits t, t+256, ... (NVT each) for the elementwise work and the four
+// block-level reductions, while wave 0 alone also holds all keys (NV0 per lane) for the exact top-k select.
+template <int NVT, int NV0>
+__global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) {
+  __shared__ float s_av[4], s_sv[4], s_f[4];
+  __shared__ int s_ai[4], s_si[4];
+  __shared__ uint32_t cand_lds[64];
+  __shared__ uint32_t s_T;
+  const int slot = blockIdx.x;
+  ArState* st = a.st + slot;
+  if (st->done) return;  // uniform
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = a.V;
+  const int pass = st->pass;
+  const float* lg = a.logits + (size_t)slot * a.logits_stride;
+  int* const tokens = a.tokens + (size_t)slot * a.tok_stride;
+  int* const sampled = a.sampled + (size_t)slot * a.tok_stride;
+  int* const argmaxes = a.argmaxes + (size_t)slot * a.tok_stride;
+  float* const xout = a.x + (size_t)slot * a.d;
+  const float* nz = st->exp_noise;
+  if (nz != nullptr) nz += (size_t)min((long long)pass, st->noise_rows - 1) * V;
+  float v[NVT], qn[NVT];
+#pragma unroll
+  for (int j = 0; j < NVT; ++j) {
+    const int i = j * 256 + tid;
+    v[j] = (i < V) ? lg[i] : -INFINITY;
+    qn[j] = (nz != nullptr && i < V) ? nz[i] : 1.f;
+  }
+  const float temp = st->temperature;
+  const int top_k = st->top_k;
+  const bool filt = top_k > 0 && top_k < V;  // uniform
+  float w0[NV0];
+  if (wave == 0 && filt) {
+#pragma unroll
+    for (int j = 0; j < NV0; ++j) w0[j] = (j * 64 + lane < V) ? lg[j * 64 + lane] : -INFINITY;
+  }
+  const unsigned long long seed = st->seed;
+  const int n_gen = st->n_gen, bos = st->bos, S = st->S, max_new = st->max_new, n_forced = st->n_forced;
+  const long long* forced = st->forced;
+  const int row = st->row + 1;
+  const float alpha = a.alpha[0];
+
+  // argmax of the raw logits (valle.py:1045); first index on ties
+  ValIdx am{v[0], tid};
+#pragma unroll
+  for (int j = 1; j < NVT; ++j) am = better(am, ValIdx{v[j], j * 256 + tid});
+  am = wave_argmax_dpp(am);
+  if (lane == 0) { s_av[wave] = am.v; s_ai[wave] = am.i; }
+  __syncthreads();
+  am = ValIdx{s_av[0], s_ai[0]};
+#pragma unroll
+  for (int w = 1; w < 4; ++w) am = better(am, ValIdx{s_av[w], s_ai[w]});
+
+  if (temp != 1.0f) {  // valle.py:1296-1297
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) v[j] = v[j] / temp;
+  }
+  uint32_t T = 0u;
+  if (filt) {
+    if (wave == 0) {
+      uint32_t key[NV0];
+#pragma unroll
+      for (int j = 0; j < NV0; ++j) {
+        const float x = (temp != 1.0f) ? w0[j] / temp : w0[j];
+        key[j] = (j * 64 + lane < V) ? order_key(x) : 0u;
+      }
+      const uint32_t t0 = topk_threshold_wave<NV0>(key, top_k, lane, cand_lds);
+      if (lane == 0) s_T = t0;
+    }
+    __syncthreads();
+    T = s_T;
+  }
+  // softmax over the kept entries: the maximum always survives the filter and x -> x / temp is monotone, so
+  // the kept maximum is the (scaled) raw maximum
+  const float mx = (temp != 1.0f) ? am.v / temp : am.v;
+  bool keep[NVT];
+  float e[NVT], zs = 0.f;
+#pragma unroll
+  for (int j = 0; j < NVT; ++j) {
+    keep[j] = (j * 256 + tid < V) && (T == 0u || order_key(v[j]) >= T);
+    e[j] = keep[j] ? expf(v[j] - mx) : 0.f;
+    zs += e[j];
+  }
+  zs = wave_sum_dpp(zs);
+  if (lane == 0) s_f[wave] = zs;
+  __syncthreads();
+  const float Z = ((s_f[0] + s_f[1]) + s_f[2]) + s_f[3];
+
+  // multinomial(p, 1) == argmax(p / q), q ~ Exp(1)
+  ValIdx sm{-1.f, 0x7fffffff};
+#pragma unroll
+  for (int j = 0; j < NVT; ++j) {
+    const int i = j * 256 + tid;
+    if (i < V) {
+      float r = 0.f;
+      if (keep[j]) r = (e[j] / Z) / ((nz != nullptr) ? qn[j] : device_exp1(seed, pass, i));
+      sm = better(sm, ValIdx{r, i});
+    }
+  }
+  sm = wave_argmax_dpp(sm);
+  if (lane == 0) { s_sv[wave] = sm.v; s_si[wave] = sm.i; }
+  __syncthreads();
+  sm = ValIdx{s_sv[0], s_si[0]};
+#pragma unroll
+  for (int w = 1; w < 4; ++w) sm = better(sm, ValIdx{s_sv[w], s_si[w]});
+
+  // stop rule + append (valle.py:1044-1057); every thread evaluates the same scalars
+  int tok = sm.i, reason = 0;
+  bool append = false, go = false;
+  if (forced != nullptr) {
+    if (pass >= n_forced) reason = 4;
+    else { tok = (int)forced[pass]; append = true; go = true; }
+  } else if (am.i == NUM_AUDIO_TOKENS) reason = 1;
+  else if (sm.i == NUM_AUDIO_TOKENS) reason = 2;
+  else if (bos + n_gen > 16 * S) reason = 3;
+  else if (max_new >= 0 && n_gen >= max_new) reason = 4;
+  else {
+    append = true; go = true;
+    if (bos + n_gen + 1 > 16 * S) { reason = 3; go = false; }
+    else if (max_new >= 0 && n_gen + 1 >= max_new) { reason = 4; go = false; }
+  }
+  if (tid == 0) {
+    sampled[pass] = sm.i;
+    argmaxes[pass] = am.i;
+    if (append) { tokens[n_gen] = tok; st->n_gen = n_gen + 1; }
+    if (reason != 0) { st->done = 1; st->stop_reason = reason; }
+    if (go) { st->row = row; st->pass = pass + 1; }
+  }
+  if (!go) return;
+  const int apos = row - S;
+  for (int c = tid * 4; c < a.d; c += 1024) {
     const float4 ev = *reinterpret_cast<const float4*>(a.emb + (size_t)tok * a.d + c);
     const float4 pv = *reinterpret_cast<const float4*>(a.pe + (size_t)apos * a.d + c);
     float4 o;

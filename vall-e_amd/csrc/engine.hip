@@ -652,7 +652,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
   sa.emb = W<float>(e, "ar_audio_embedding.word_embeddings.weight");
   sa.alpha = W<float>(e, "ar_audio_position.alpha");
   sa.pe = e->pe_ar; sa.x = e->ar_x; sa.d = d;
-  sample_embed_kernel<17><<<1, 64, 0, s>>>(sa);
+  sample_embed4_kernel<5, 17><<<1, 256, 0, s>>>(sa);
   const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd * e->esz;
   const float scale = 1.0f / sqrtf((float)hd);
   for (int li = 0; li < c.num_layers; ++li) {
@@ -829,7 +829,7 @@ static int enqueue_batch_step(vx_engine* e, int B, hipStream_t s) {
   sa.alpha = W<float>(e, "ar_audio_position.alpha");
   sa.pe = e->pe_ar; sa.x = e->bx; sa.d = d;
   sa.logits_stride = LOGITS_CUR; sa.tok_stride = e->btok_stride;
-  sample_embed_kernel<17><<<B, 64, 0, s>>>(sa);
+  sample_embed4_kernel<5, 17><<<B, 256, 0, s>>>(sa);
   const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd;  // elements
   const float scale = 1.0f / sqrtf((float)hd);
   const int lnb = (B + 3) / 4;
@@ -1292,7 +1292,9 @@ extern "C" int vx_op_sample(const float* logits, int32_t V, int32_t top_k, float
   sa.logits = logits; sa.V = V; sa.st = dst;
   sa.tokens = scratch; sa.sampled = scratch + 4; sa.argmaxes = scratch + 8;
   sa.emb = fz; sa.alpha = fz; sa.pe = fz; sa.x = fz + 2048; sa.d = 0;
-  if (V <= 17 * 64) sample_embed_kernel<17><<<1, 64, 0, s>>>(sa);
+  // both variants are exercised by the parity test: the 4-wave kernel of the decode step for the model's vocabulary,
+  // the single-wave one for larger test vocabularies
+  if (V <= 17 * 64) sample_embed4_kernel<5, 17><<<1, 256, 0, s>>>(sa);
   else sample_embed_kernel<32><<<1, 64, 0, s>>>(sa);
   HIPC(hipGetLastError());
   int host[16];
