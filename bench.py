@@ -120,6 +120,7 @@ def main():
         mine = scatter_utterances([utts[(s * world + r) * Bt + j] for s in step_ids for j in range(Bt) for r in range(world)]
                                   if rank == 0 else None, len(step_ids) * Bt, dev, world, rank)
         outs, frames = [], 0
+        tms = []
         if Bt > 1:
             for i in range(len(step_ids)):
                 group = mine[i * Bt : (i + 1) * Bt]
@@ -127,14 +128,16 @@ def main():
                                             seeds=[1234 + (step_ids[i] * world + rank) * Bt + j for j in range(Bt)])
                 outs += res
                 frames += sum(c.shape[1] for c in res)
+                tms.append(eng.timings())
         else:
             for i, (x, x_lens, y) in enumerate(mine):
                 torch.manual_seed(1234 + step_ids[i] * world + rank)  # seeds the on-device sampler
                 codes = model.inference(x, x_lens, y, None, top_k=TOP_K, temperature=TEMP)
                 outs.append(codes)
                 frames += codes.shape[1]
+                tms.append(eng.timings())
         gather_codes(outs, dev, world, rank)
-        return frames, outs
+        return frames, outs, tms
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -145,7 +148,7 @@ def main():
     run_phase(list(range(args.warmup)))
     fence()
     t0 = time.perf_counter()
-    frames, outs = run_phase(list(range(args.warmup, n_total)))
+    frames, outs, tms = run_phase(list(range(args.warmup, n_total)))
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt, float(frames)], dtype=torch.float64, device=dev)
@@ -155,7 +158,13 @@ def main():
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, frames = float(tmax[0]), float(tsum[1])
-    tm = eng.timings()  # HIP-event device times of this rank's LAST utterance (engine stream)
+    # HIP-event device times (engine stream) of every timed step on this rank: totals for the AR step, p50 for NAR
+    import statistics
+    tm = dict(tms[-1])
+    for k in ("decode_ms", "launches", "batch_decode_ms", "batch_launches"):
+        tm[k] = sum(t[k] for t in tms)
+    tm["nar_ms"] = statistics.median(t["nar_ms"] for t in tms)
+    tm["prefill_ms"] = statistics.median(t["prefill_ms"] for t in tms)
 
     if rank == 0:
         T = outs[-1].shape[1]
@@ -185,7 +194,7 @@ def main():
             "ar_tokens_per_s": round(tm["launches"] / (tm["decode_ms"] * 1e-3), 1),
             "ar_step_us": round(step_s * 1e6, 2),
             "prefill_ms": round(tm["prefill_ms"], 3),
-            "nar_7stage_ms": round(tm["nar_ms"], 3),
+            "nar_7stage_ms": round(tm["nar_ms"], 3),  # p50 over the timed steps
             "roofline": {"bound": "hbm", "kernel": "AR decode step (hipGraph of 62 kernels = 1 token)" if Bt == 1 else
                          f"batched AR decode step (hipGraph of 87 kernels = {Bt} tokens)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
