@@ -23,6 +23,6 @@ def bench(M, N, K, iters=30):
     return us, 2.0 * M * N * K / us / 1e6
 
 alg = os.environ.get("VX_GEMM_ALG", "0")
-for (M, N, K) in [(1025, 3072, 1024), (1025, 4096, 1024), (1025, 1024, 1024), (1025, 1024, 4096), (2050, 3072, 1024), (4100, 3072, 1024), (8200, 3072, 1024), (4096, 4096, 4096)]:
+for (M, N, K) in [(1025, 3072, 1024), (1025, 4096, 1024), (1025, 1024, 1024), (1025, 1024, 4096), (2050, 3072, 1024), (4100, 3072, 1024), (8200, 3072, 1024), (4096, 4096, 4096), (33000, 3072, 1024), (33000, 1024, 4096), (33000, 4096, 1024), (33000, 1024, 1024)]:
     us, tf = bench(M, N, K)
     print(json.dumps(dict(alg=alg, M=M, N=N, K=K, us=round(us, 1), tflops=round(tf, 1))), flush=True)

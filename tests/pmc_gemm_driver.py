@@ -1,0 +1,28 @@
+"""Torch-free driver: one bf16 GEMM through vx_op_gemm for rocprofv3 --pmc (traffic / MFMA counters).
+usage: python3 tests/pmc_gemm_driver.py M N K [iters]   (VX_GEMM_ALG selects the kernel)"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+hip = C.CDLL("libamdhip64.so")
+lib = C.CDLL(os.path.join(ROOT, "vall-e_amd", "csrc", "libvallex.so"))
+lib.vx_last_error.restype = C.c_char_p
+M, N, K = (int(v) for v in sys.argv[1:4])
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+
+
+def dmalloc(nbytes, fill=0x3c):
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+    assert hip.hipMemset(p, fill, C.c_size_t(nbytes)) == 0  # 0x3c3c = bf16 0.0115: finite, non-zero
+    return p
+
+
+A, W, bias, Cm = dmalloc(M * K * 2), dmalloc(N * K * 2), dmalloc(N * 4, 0), dmalloc(M * N * 4, 0)
+lib.vx_op_gemm.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]
+for _ in range(iters):
+    rc = lib.vx_op_gemm(1, 1, A, W, bias, Cm, M, N, K, 0, None)
+    assert rc == 0, lib.vx_last_error()
+assert hip.hipDeviceSynchronize() == 0
+print("ok", M, N, K)

@@ -63,7 +63,7 @@ def test_gemm_fp32(eng, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(272, 3072, 1024), (1025, 1024, 4096), (100, 384, 128), (753, 1024, 1024), (128, 128, 64),
-                                   (1, 256, 256)])
+                                   (1, 256, 256), (4133, 512, 256), (4096, 768, 1024), (4700, 256, 64)])
 @pytest.mark.parametrize("mfma", [False, True])
 def test_gemm_bf16(eng, M, N, K, mfma):
     A, W, b = _rand(M, K, seed=1).to(torch.bfloat16), _rand(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16), _rand(N, seed=3)

@@ -285,6 +285,153 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const bf16* __restrict__ A, 
   }
 }
 
+// ---- 256x256 tile, direct-to-LDS operand staging, 4-stage pipeline: the large-M GEMM (batched NAR, M ~ 33 k) ----
+// 8 waves as 2(M) x 4(N), each 128x64 of output on v_mfma_f32_16x16x32_bf16 (8 x 4 fragments, 128
+// accumulator registers).  Per 64 of K a CU multiplies 8.4 MFLOP (2048 MFMA cycles per SIMD) and moves 64 KB
+// through the texture path: half the bytes per FLOP of the 128^2 tile.
+//  * Operands go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write).  The LDS image is
+//    lane-linear, so the bank swizzle is applied to the SOURCE address and again on the read (guide rule 21).
+//  * K is consumed in stages of 32 (rows of 64 B), FOUR LDS buffers of 32 KB: while stage t is multiplied, stages
+//    t+1..t+3 are in flight.  hipcc would drain LDS-DMA with vmcnt(0) at every __syncthreads(), so the loop uses a
+//    counted `s_waitcnt vmcnt(4)` (= the youngest stage stays in flight) + raw s_barrier; the loads past the
+//    end of K are clamped, not skipped, so the count is the same in every iteration.
+//  * Chunk swizzle for 64-byte rows: slot = chunk ^ ((row >> 2) & 3): the 16 rows of a ds_read_b128 lane group
+//    land on 16 distinct 16-byte slots of the 256-byte bank row.
+//  * The MFMA is issued as W-fragment x A-fragment, so the accumulator has m on the lane and 4 consecutive n in
+//    its registers: the epilogue stores 8 / 16 bytes per lane instead of 4 x 2-byte pieces.
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                                      const float* __restrict__ bias, void* __restrict__ Cv, int M, int N,
+                                                      int K, bf16* __restrict__ vt, int vt_n0, int vt_ld, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [4 stages][A 16 KB | W 16 KB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 15, g = lane >> 4;
+  // XCD-aware tile order: blocks with equal blockIdx % 8 (one XCD under round-robin placement; speed only) walk a
+  // contiguous run of tiles, n fastest, so concurrent neighbours share A rows / W rows in that XCD's L2
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int q8 = nblk >> 3, r8 = nblk & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  const int mt = tile / ntn, nt = tile - mt * ntn;
+  const int m0 = mt * 256, n0 = nt * 256;
+
+  f32x4v_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+
+  // one stage = 2048 16-byte slots (A: 1024, W: 1024), 4 per thread; slot q -> row q>>2, position q&3 holds
+  // source chunk (q&3) ^ ((row>>2)&3)
+  const int q0 = tid, q1 = tid + 512;
+  const int rowa0 = q0 >> 2, rowa1 = q1 >> 2;
+  const int ca0 = ((q0 & 3) ^ ((rowa0 >> 2) & 3)) * 8, ca1 = ((q1 & 3) ^ ((rowa1 >> 2) & 3)) * 8;
+  const bf16* srcA0 = A + (size_t)min(m0 + rowa0, M - 1) * K + ca0;
+  const bf16* srcA1 = A + (size_t)min(m0 + rowa1, M - 1) * K + ca1;
+  const bf16* srcW0 = W + (size_t)min(n0 + rowa0, N - 1) * K + ca0;
+  const bf16* srcW1 = W + (size_t)min(n0 + rowa1, N - 1) * K + ca1;
+  const int d0 = (q0 - lane) * 16, d1 = (q1 - lane) * 16;  // wave-uniform LDS slot of lane 0
+  const int kmax = K - 32;
+  auto stage = [&](int buf, int k0) {
+    k0 = min(k0, kmax);
+    unsigned char* base = lds + buf * 32768;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA0 + k0),
+                                     (__attribute__((address_space(3))) void*)(base + d0), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA1 + k0),
+                                     (__attribute__((address_space(3))) void*)(base + d1), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW0 + k0),
+                                     (__attribute__((address_space(3))) void*)(base + 16384 + d0), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW1 + k0),
+                                     (__attribute__((address_space(3))) void*)(base + 16384 + d1), 16, 0, 0);
+  };
+
+  const int nk = K / 32;
+  // fragments of one stage: 4 W + 8 A ds_read_b128 per lane.  Two register sets: the reads of stage t+1 are issued
+  // right before the MFMAs of stage t, so the LDS phase of one stage overlaps the matrix phase of the previous one
+  // (both waves of a SIMD otherwise run their LDS and MFMA phases in lockstep and the phases add up).
+  bf16x8_t fbA[4], faA[8], fbB[4], faB[8];
+  auto lread = [&](int buf, bf16x8_t (&fb)[4], bf16x8_t (&fa)[8]) {
+    const unsigned char* ba = lds + buf * 32768;
+    const unsigned char* bw = ba + 16384;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wn * 64 + j * 16 + r;
+      fb[j] = *reinterpret_cast<const bf16x8_t*>(bw + row * 64 + ((g ^ ((row >> 2) & 3)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = wm * 128 + i * 16 + r;
+      fa[i] = *reinterpret_cast<const bf16x8_t*>(ba + row * 64 + ((g ^ ((row >> 2) & 3)) << 4));
+    }
+  };
+  auto mm = [&](const bf16x8_t (&fb)[4], const bf16x8_t (&fa)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+  };
+  // iteration t: [issue stage t+3] [read fragments of stage t+1] [MFMAs of stage t] [vmcnt(4): stage t+2 landed] [barrier]
+  // LDS buffer (t+3)&3 was last read (as stage t-1) in iteration t-2: two barriers ago.
+  stage(0, 0);
+  stage(1, 32);
+  stage(2, 64);
+  asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // stages 0 and 1 landed everywhere
+  lread(0, fbA, faA);
+  int t = 0;
+  for (; t + 2 <= nk; t += 2) {
+    stage((t + 3) & 3, (t + 3) * 32);
+    lread((t + 1) & 3, fbB, faB);
+    mm(fbA, faA);
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    stage((t + 4) & 3, (t + 4) * 32);
+    lread((t + 2) & 3, fbA, faA);
+    mm(fbB, faB);
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+  }
+  if (t < nk) mm(fbA, faA);  // odd stage count
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail stages
+
+  // epilogue: acc[i][j][v] = C[m = m0 + wm*128 + i*16 + r][n = n0 + wn*64 + j*16 + 4g + v]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int nb = n0 + wn * 64 + j * 16 + 4 * g;  // N % 256 == 0: always in range
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI != GE_PLAIN) bv = *reinterpret_cast<const float4*>(bias + nb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wm * 128 + i * 16 + r;
+      float x[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+      if (EPI == GE_RELU) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) x[v] = fmaxf(x[v], 0.f);
+      }
+      if (m < M) {
+        if (OUT_F32) {
+          float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (size_t)m * N + nb);
+          if (EPI == GE_RESID) {
+            const float4 o = *cp;
+            *cp = make_float4(o.x + x[0], o.y + x[1], o.z + x[2], o.w + x[3]);
+          } else {
+            *cp = make_float4(x[0], x[1], x[2], x[3]);
+          }
+        } else {
+          union { bf16 e[4]; uint2 u; } pk;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) pk.e[v] = (bf16)x[v];
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(Cv) + (size_t)m * N + nb) = pk.u;
+          if (vt != nullptr && nb >= vt_n0) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) vt[(size_t)(nb + v - vt_n0) * vt_ld + m] = pk.e[v];
+          }
+        }
+      }
+    }
+  }
+}
+
 static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* bias, void* C, int M, int N, int K,
                                      int epi, bool out_f32, hipStream_t s, bf16* vt = nullptr, int vt_n0 = 0,
                                      int vt_ld = 0) {
@@ -303,6 +450,28 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
   // 1 / 2 force one or the other (A/B runs)
   static const int alg = [] { const char* v = getenv("VX_GEMM_ALG"); return v ? atoi(v) : 0; }();
   const long long tiles64 = (long long)((M + 63) / 64) * (N / 64);
+  if (alg == 3 || (alg == 0 && N % 256 == 0 && K % 32 == 0 && K >= 128 && M >= 4096)) {  // enough 256^2 tiles for several per CU
+    const int ntn = N / 256, ntm = (M + 255) / 256;
+#define M2(E, F)                                                                                                         \
+  do {                                                                                                                  \
+    static bool attr_done = false;                                                                                      \
+    if (!attr_done) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)mfma256_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);  \
+      attr_done = true;                                                                                                 \
+    }                                                                                                                   \
+    mfma256_kernel<E, F><<<ntn * ntm, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn);                   \
+  } while (0)
+    if (N % 256 == 0) {
+      if (epi == GE_RESID) M2(GE_RESID, true);
+      else if (epi == GE_PLAIN) M2(GE_PLAIN, true);
+      else if (epi == GE_BIAS && out_f32) M2(GE_BIAS, true);
+      else if (epi == GE_RELU && out_f32) M2(GE_RELU, true);
+      else if (epi == GE_BIAS) M2(GE_BIAS, false);
+      else M2(GE_RELU, false);
+      return 0;
+    }
+#undef M2
+  }
   if (alg == 1 || (alg == 0 && N % 128 == 0 && tiles64 >= 512)) {
     dim3 grid((N + 127) / 128, (M + 127) / 128);
 #define MG(E, F)                                                                                                        \
