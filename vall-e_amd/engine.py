@@ -66,6 +66,7 @@ _SIGS = {
     "vx_op_sample": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "vx_op_convert_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "vx_debug_launch_floor": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    "vx_debug_stage_chain": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_double)]),
 }
 
 
@@ -327,3 +328,10 @@ def launch_floor(n_kernels=62, grid=256, block=256, iters=200):
     out = (C.c_double * 2)()
     _check(lib.vx_debug_launch_floor(n_kernels, grid, block, iters, out))
     return dict(graph_us_per_kernel=out[0], eager_us_per_kernel=out[1])
+
+
+def stage_chain(nwg=256, stages=60, rows=12, mode=2, iters=20):
+    lib = load_library()
+    out = (C.c_double * 4)()
+    _check(lib.vx_debug_stage_chain(nwg, stages, rows, mode, iters, out))
+    return dict(us_per_launch=out[0], us_per_stage=out[1], max_err=out[2], spin_timeout=int(out[3]))
