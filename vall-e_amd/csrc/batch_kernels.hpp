@@ -95,62 +95,49 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
   }
 }
 
-// x[b] += bias + sum_g part[g][b] (optional; written back), then h[b] = bf16(LN(x[b]) * gamma + beta).
-// One wave per slot.
-__global__ __launch_bounds__(256) void ln_batch_kernel(float* __restrict__ x, const float* __restrict__ part, int kgroups,
+// x[b] += bias + sum_g part[g][b] (KG > 0; written back), then h[b] = bf16(LN(x[b]) * gamma + beta).
+// One workgroup per slot, thread t owns columns [4t, 4t+4): every load of the kernel (x, bias, the KG partials,
+// gamma, beta) is issued up front, so the kernel is one memory round trip plus two workgroup reductions.
+template <int KG>
+__global__ __launch_bounds__(256) void ln_batch_kernel(float* __restrict__ x, const float* __restrict__ part,
                                                        const float* __restrict__ pbias, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, bf16* __restrict__ h, int B, int d) {
-  constexpr int MAXV = 4;  // d <= 1024
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= B) return;
+                                                       const float* __restrict__ beta, bf16* __restrict__ h, int d) {
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const bool live = tid * 4 < d;
+  const int k = live ? tid * 4 : 0;  // idle threads (d < 1024) load column 0 and contribute zeros
   float* xr = x + (size_t)b * d;
-  float4 v[MAXV];
-  float s = 0.f;
+  float4 v = *reinterpret_cast<const float4*>(xr + k);
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + k);
+  const float4 bt = *reinterpret_cast<const float4*>(beta + k);
+  if (KG > 0) {
+    float4 t = *reinterpret_cast<const float4*>(pbias + k);
+    float4 p[KG > 0 ? KG : 1];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int k = (i * 64 + lane) * 4;
-    if (k < d) {
-      v[i] = *reinterpret_cast<const float4*>(xr + k);
-      if (part != nullptr) {
-        const float4 pb = *reinterpret_cast<const float4*>(pbias + k);
-        float4 t = pb;
-        for (int gi = 0; gi < kgroups; ++gi) {
-          const float4 p = *reinterpret_cast<const float4*>(part + ((size_t)gi * BMAX + b) * d + k);
-          t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
-        }
-        v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
-        *reinterpret_cast<float4*>(xr + k) = v[i];
-      }
-    } else {
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    for (int gi = 0; gi < KG; ++gi) p[gi] = *reinterpret_cast<const float4*>(part + ((size_t)gi * BMAX + b) * d + k);
+#pragma unroll
+    for (int gi = 0; gi < KG; ++gi) { t.x += p[gi].x; t.y += p[gi].y; t.z += p[gi].z; t.w += p[gi].w; }
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    if (live) *reinterpret_cast<float4*>(xr + k) = v;
   }
-  const float mean = wave_sum_dpp(s) / (float)d;
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int k = (i * 64 + lane) * 4;
-    if (k < d) {
-      const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
-      ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum_dpp(ss) / (float)d + LN_EPS);
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int k = (i * 64 + lane) * 4;
-    if (k < d) {
-      const float4 gm = *reinterpret_cast<const float4*>(gamma + k);
-      const float4 bt = *reinterpret_cast<const float4*>(beta + k);
-      union { bf16 e[4]; uint2 u; } pk;
-      pk.e[0] = (bf16)((v[i].x - mean) * rstd * gm.x + bt.x);
-      pk.e[1] = (bf16)((v[i].y - mean) * rstd * gm.y + bt.y);
-      pk.e[2] = (bf16)((v[i].z - mean) * rstd * gm.z + bt.z);
-      pk.e[3] = (bf16)((v[i].w - mean) * rstd * gm.w + bt.w);
-      *reinterpret_cast<uint2*>(h + (size_t)b * d + k) = pk.u;
-    }
+  if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float s = wave_sum_dpp((v.x + v.y) + (v.z + v.w));
+  if (lane == 0) red[0][wave] = s;
+  __syncthreads();
+  const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)d;
+  const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+  const float ss = wave_sum_dpp(live ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f);
+  if (lane == 0) red[1][wave] = ss;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)d + LN_EPS);
+  if (live) {
+    union { bf16 e[4]; uint2 u; } pk;
+    pk.e[0] = (bf16)(d0 * rstd * gm.x + bt.x);
+    pk.e[1] = (bf16)(d1 * rstd * gm.y + bt.y);
+    pk.e[2] = (bf16)(d2 * rstd * gm.z + bt.z);
+    pk.e[3] = (bf16)(d3 * rstd * gm.w + bt.w);
+    *reinterpret_cast<uint2*>(h + (size_t)b * d + k) = pk.u;
   }
 }
 
@@ -162,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_batch_kernel(const float* __restrict
                                                          size_t kv_slot_stride, size_t kv_v_offset,
                                                          const ArState* __restrict__ st, int ctx_max, int d, float scale,
                                                          bf16* __restrict__ out) {
-  constexpr int VEC = 8, LPK = HD / VEC, KPW = 64 / LPK, KPB = 4 * KPW, UNR = 6;
+  constexpr int VEC = 8, LPK = HD / VEC, KPW = 64 / LPK, KPB = 4 * KPW, UNR = 4;
   __shared__ float sm_red[4];
   __shared__ __attribute__((aligned(16))) float sm_o[4 * KPW][HD + 1];
   __shared__ float sm_l[4 * KPW];
@@ -181,14 +168,21 @@ __global__ __launch_bounds__(256) void attn_batch_kernel(const float* __restrict
   float M = -INFINITY, L = 0.f, acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-  for (int base = 0; base < ctx; base += UNR * KPB) {
-    uint4 kr[UNR], vr[UNR];
+  constexpr int STEP = UNR * KPB;
+  // Two register sets: the loads of pass p+1 are in flight while pass p is scored.  They are issued
+  // unconditionally on clamped rows (the pass after the last re-reads the last key and is never scored), so the
+  // loop body has no branch around a load and the waits stay counted.
+  uint4 kr0[UNR], vr0[UNR], kr1[UNR], vr1[UNR];
+  auto issue = [&](uint4 (&kr)[UNR], uint4 (&vr)[UNR], int base) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int j = min(base + u * KPB + wave * KPW + grp, ctx - 1);
       kr[u] = ld16(kb + (size_t)j * HD);
       vr[u] = ld16(vb + (size_t)j * HD);
     }
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads here, ahead of the scoring of the other set
+  };
+  auto score = [&](const uint4 (&kr)[UNR], const uint4 (&vr)[UNR], int base) {
     float sc[UNR], mloc = -INFINITY;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -222,6 +216,17 @@ __global__ __launch_bounds__(256) void attn_batch_kernel(const float* __restrict
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] = fmaf(p, vf[i], acc[i]);
     }
+  };
+  issue(kr0, vr0, 0);
+  for (int base = 0;;) {
+    issue(kr1, vr1, base + STEP);
+    score(kr0, vr0, base);
+    base += STEP;
+    if (base >= ctx) break;
+    issue(kr0, vr0, base + STEP);
+    score(kr1, vr1, base);
+    base += STEP;
+    if (base >= ctx) break;
   }
   const int gi = wave * KPW + grp;
 #pragma unroll

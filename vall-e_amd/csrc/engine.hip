@@ -818,6 +818,12 @@ template <int EPI> static int launch_bgemm(const BgemmArgs& a, hipStream_t s) {
   return VX_OK;
 }
 static int kgroups_for(int K) { return (K / 128) >= 4 ? 4 : 1; }
+static void launch_ln_batch(float* x, const float* part, int kgroups, const float* pbias, const float* gamma, const float* beta,
+                            bf16* h, int B, int d, hipStream_t s) {
+  if (part == nullptr) ln_batch_kernel<0><<<B, 256, 0, s>>>(x, nullptr, nullptr, gamma, beta, h, d);
+  else if (kgroups == 4) ln_batch_kernel<4><<<B, 256, 0, s>>>(x, part, pbias, gamma, beta, h, d);
+  else ln_batch_kernel<1><<<B, 256, 0, s>>>(x, part, pbias, gamma, beta, h, d);
+}
 
 // One batched step: every slot samples its next token, then the L layers run once over all B slots.
 static int enqueue_batch_step(vx_engine* e, int B, hipStream_t s) {
@@ -833,14 +839,12 @@ static int enqueue_batch_step(vx_engine* e, int B, hipStream_t s) {
   sample_embed4_kernel<5, 17><<<B, 256, 0, s>>>(sa);
   const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd;  // elements
   const float scale = 1.0f / sqrtf((float)hd);
-  const int lnb = (B + 3) / 4;
   const int kg_d = kgroups_for(d), kg_ff = kgroups_for(4 * d);
   for (int li = 0; li < L; ++li) {
     const LayerW& l = e->ar_l[li];
     // LN1 (+ the FFN2 partial sums of the previous layer)
     const bool prev = li > 0;
-    ln_batch_kernel<<<lnb, 256, 0, s>>>(e->bx, prev ? e->bpart : nullptr, kg_ff, prev ? e->ar_l[li - 1].b2 : nullptr,
-                                        l.n1_g, l.n1_b, e->bh, B, d);
+    launch_ln_batch(e->bx, prev ? e->bpart : nullptr, kg_ff, prev ? e->ar_l[li - 1].b2 : nullptr, l.n1_g, l.n1_b, e->bh, B, d, s);
     BgemmArgs a{};
     a.st = e->bst; a.B = B; a.d = d; a.hd = hd; a.ctx_max = e->ctx_max;
     a.A = e->bh; a.W = (const bf16*)l.in_w; a.bias = l.in_b; a.N = 3 * d; a.K = d; a.kgroups = 1;
@@ -852,7 +856,7 @@ static int enqueue_batch_step(vx_engine* e, int B, hipStream_t s) {
     o.st = e->bst; o.B = B;
     o.A = e->batt; o.W = (const bf16*)l.out_w; o.N = d; o.K = d; o.kgroups = kg_d; o.part = e->bpart;
     VXC(launch_bgemm<BE_PARTIAL>(o, s));
-    ln_batch_kernel<<<lnb, 256, 0, s>>>(e->bx, e->bpart, kg_d, l.out_b, l.n2_g, l.n2_b, e->bh, B, d);
+    launch_ln_batch(e->bx, e->bpart, kg_d, l.out_b, l.n2_g, l.n2_b, e->bh, B, d, s);
     BgemmArgs f{};
     f.st = e->bst; f.B = B;
     f.A = e->bh; f.W = (const bf16*)l.w1; f.bias = l.b1; f.N = 4 * d; f.K = d; f.kgroups = 1; f.f = e->bff;
@@ -862,8 +866,8 @@ static int enqueue_batch_step(vx_engine* e, int B, hipStream_t s) {
     g.A = e->bff; g.W = (const bf16*)l.w2; g.N = d; g.K = 4 * d; g.kgroups = kg_ff; g.part = e->bpart;
     VXC(launch_bgemm<BE_PARTIAL>(g, s));
   }
-  ln_batch_kernel<<<lnb, 256, 0, s>>>(e->bx, e->bpart, kg_ff, e->ar_l[L - 1].b2, W<float>(e, "ar_decoder.norm.weight"),
-                                      W<float>(e, "ar_decoder.norm.bias"), e->bh, B, d);
+  launch_ln_batch(e->bx, e->bpart, kg_ff, e->ar_l[L - 1].b2, W<float>(e, "ar_decoder.norm.weight"),
+                  W<float>(e, "ar_decoder.norm.bias"), e->bh, B, d, s);
   BgemmArgs hgm{};
   hgm.st = e->bst; hgm.B = B;
   hgm.A = e->bh; hgm.W = W<bf16>(e, "ar_predict_layer.weight"); hgm.N = AR_VOCAB; hgm.K = d; hgm.kgroups = 1;
