@@ -381,14 +381,31 @@ __global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A
   asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // stages 0 and 1 landed everywhere
   lread(0, fbA, faA);
   int t = 0;
+  // issue order inside one half-iteration: the 4 LDS-DMA loads and the 12 fragment reads of the NEXT stage are
+  // spread between the 32 MFMAs of the current one (1 memory instruction per 2 MFMAs) instead of being bunched in
+  // front of them, so the LDS and matrix pipes run concurrently within a wave too
+  auto interleave = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // VMEM
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+  };
   for (; t + 2 <= nk; t += 2) {
     stage((t + 3) & 3, (t + 3) * 32);
     lread((t + 1) & 3, fbB, faB);
     mm(fbA, faA);
+    interleave();
     asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     stage((t + 4) & 3, (t + 4) * 32);
     lread((t + 2) & 3, fbA, faA);
     mm(fbB, faB);
+    interleave();
     asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
   }
   if (t < nk) mm(fbA, faA);  // odd stage count
