@@ -138,6 +138,11 @@ int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* pro
  * with vx_nar. */
 int vx_batch_prefill(vx_engine* e, int32_t slot, const int64_t* text, int32_t S, const int64_t* prompt_cb0, int32_t P,
                      void* stream);
+/* All n slots' prefills in one pass over the concatenated rows (slot z = utterance z): same contract as n calls of
+ * vx_batch_prefill(z, text[z], S[z], prompt_cb0[z], P[z]); bf16 engines only.  The pointer arrays and S / P live on
+ * the host, text[z] / prompt_cb0[z] may be host or device pointers. */
+int vx_batch_prefill_all(vx_engine* e, int32_t n, const int64_t* const* text, const int32_t* S,
+                         const int64_t* const* prompt_cb0, const int32_t* P, void* stream);
 int vx_batch_decode(vx_engine* e, int32_t n_slots, const vx_decode_params* params, void* stream);
 int vx_batch_result(vx_engine* e, int32_t slot, int64_t* tokens, int32_t capacity, int32_t* n_tokens,
                     int32_t* stop_reason);

@@ -162,3 +162,37 @@ def test_batched_nar_matches_per_utterance_nar_and_reference():
         assert torch.equal(a, b)
     # the single-utterance path still works after the row buffers were regrown
     assert torch.equal(eng.nar(texts[0], proms[0], tks[0]).cpu(), single[0])
+
+
+def test_batched_prefill_matches_per_slot_prefill():
+    """vx_batch_prefill_all (one pass over the concatenated rows, per-segment prefix mask, K/V scattered straight into
+    every slot's cache) against n calls of vx_batch_prefill: same first logits within the bf16 tolerance, and the
+    teacher-forced decode that follows reads the same caches (per-pass argmax agreement)."""
+    cfg, sd, m = _setup(max_batch=4)
+    eng = m.engine()
+    utts = _utts([(6, 30), (9, 70), (4, 55), (11, 129)])
+    texts = [u[0][0] for u in utts]
+    proms = [u[2][0, :, 0].contiguous() for u in utts]
+    forced = [torch.randint(0, 1024, (24,), generator=torch.Generator().manual_seed(5 + i)).cuda() for i in range(4)]
+
+    for b in range(4):
+        eng.batch_prefill(b, texts[b], proms[b])
+    lg_ref = eng.read("batch_logits", (32, 1088))[:4, :1025].clone()
+    eng.batch_decode(4, top_k=1, forced=forced)
+    arg_ref = eng.read("batch_argmax", (32, eng.max_audio + 2), dtype=torch.int32)[:4, :24].clone()
+
+    eng.batch_prefill_all(texts, proms)
+    lg = eng.read("batch_logits", (32, 1088))[:4, :1025].clone()
+    eng.batch_decode(4, top_k=1, forced=forced)
+    arg = eng.read("batch_argmax", (32, eng.max_audio + 2), dtype=torch.int32)[:4, :24].clone()
+
+    for b in range(4):
+        err = float((lg[b] - lg_ref[b]).abs().max())
+        assert err <= 0.03 * float(lg_ref[b].abs().max()), (b, err)
+    assert (arg == arg_ref).float().mean().item() >= 0.97
+    # whole path through inference_batch with either prefill: every slot stops by its own length rule
+    a = m.inference_batch(utts[:2], top_k=1, batched_prefill=True)
+    b2 = m.inference_batch(utts[:2], top_k=1, batched_prefill=False)
+    for x, y, u in zip(a, b2, utts):
+        assert x.shape == y.shape == (1, 16 * u[0].shape[1] + 1, 8)
+        assert int(x.min()) >= 0 and int(x.max()) < 1024

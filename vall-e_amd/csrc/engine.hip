@@ -107,7 +107,11 @@ struct vx_engine {
   int *btok = nullptr, *bsamp = nullptr, *bargm = nullptr;
   int btok_stride = 0;
   std::unordered_map<int, hipGraphExec_t> bgraphs;
-  int *d_seg_start = nullptr, *d_seg_len = nullptr;  // batched NAR segments
+  int *d_seg_start = nullptr, *d_seg_len = nullptr;  // segments of the concatenated row buffer (batched NAR / prefill)
+  int* d_seg_text = nullptr;                          // per-segment text length (prefix mask of a batched prefill)
+  bool seg_text_on = false;                           // true only while a batched prefill runs its stack
+  long long *bp_text = nullptr, *bp_audio = nullptr;  // id staging of the batched prefill
+  size_t cap_audio = 0, cap_text = 0;                 // rows the id / yemb / logits staging buffers hold
   int nseg = 0, max_seg_len = 0;
   int bS[BMAX] = {}, bP[BMAX] = {}, bbos[BMAX] = {}, bngen[BMAX] = {}, breason[BMAX] = {};
   bool bprefilled[BMAX] = {};
@@ -274,6 +278,7 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   VXC(dalloc_t(e, &e->ids_prompts, (size_t)c.max_audio * 8));
   VXC(dalloc_t(e, &e->ids_samples, (size_t)c.max_audio));
   VXC(dalloc_t(e, &e->d_codes, (size_t)c.max_audio * 8));
+  e->cap_audio = c.max_audio; e->cap_text = c.max_text;
   if (c.max_batch > 1) {
     e->bmax = c.max_batch;
     e->btok_stride = c.max_audio + 2;
@@ -291,6 +296,11 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
     VXC(dalloc_t(e, &e->bsamp, (size_t)BMAX * e->btok_stride));
     VXC(dalloc_t(e, &e->bargm, (size_t)BMAX * e->btok_stride));
     HIPC(hipHostMalloc((void**)&e->h_bst, 3 * BMAX * sizeof(ArState)));
+    VXC(dalloc_t(e, &e->bp_text, (size_t)BMAX * c.max_text));
+    VXC(dalloc_t(e, &e->bp_audio, (size_t)BMAX * (c.max_audio + 1)));
+    VXC(dalloc_t(e, &e->d_seg_start, (size_t)BMAX));
+    VXC(dalloc_t(e, &e->d_seg_len, (size_t)BMAX));
+    VXC(dalloc_t(e, &e->d_seg_text, (size_t)BMAX));
     // MFMA A operands always read 32 rows: rows of unused slots must hold finite values
     HIPC(hipMemset(e->bx, 0, (size_t)BMAX * d * 4));
     HIPC(hipMemset(e->bh, 0, (size_t)BMAX * d * 2));
@@ -501,7 +511,7 @@ static int attn_rows(vx_engine* e, const void* qkv, void* out, int M, int d, int
   const float scale = 1.0f / sqrtf(64.0f);
   if (e->nseg > 0)  // batched NAR: one launch over all segments of the concatenated rows
     return mfma_attn_dispatch((const bf16*)qkv, (const bf16*)e->VT, e->vt_ld, (bf16*)out, M, d, H, text_len, e->es,
-                              e->d_seg_start, e->d_seg_len, e->nseg, e->max_seg_len);
+                              e->d_seg_start, e->d_seg_len, e->nseg, e->max_seg_len, e->seg_text_on ? e->d_seg_text : nullptr);
   if (use_mfma(e)) return mfma_attn_dispatch((const bf16*)qkv, (const bf16*)e->VT, e->vt_ld, (bf16*)out, M, d, H, text_len, e->es);
   dim3 grid((M + 63) / 64, H);
   if (e->bf16) attn_rows_simple_kernel<bf16, 64><<<grid, 256, 0, e->es>>>((const bf16*)qkv, (bf16*)out, M, d, text_len, scale);
@@ -525,7 +535,11 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
     }
     VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d));
     VXC(gemm_rows(e, e->Hn, l.in_w, l.in_b, e->QKV, M, 3 * d, d, GE_BIAS, false, use_mfma(e)));
-    if (fill_cache) {
+    if (fill_cache && e->nseg > 0) {  // batched prefill: segment z -> slot z
+      const size_t kvl = (size_t)2 * H * e->ctx_max * 64;  // elements per layer
+      kv_scatter_seg_kernel<bf16><<<dim3(e->max_seg_len, e->nseg), 256, 0, e->es>>>(
+          (const bf16*)e->QKV, e->bkv + li * kvl, e->bkv_slot, kvl / 2, e->d_seg_start, e->d_seg_len, d, 64, e->ctx_max);
+    } else if (fill_cache) {
       char* kc = kv_base + li * kv_layer;
       char* vc = kc + kv_layer / 2;
       if (e->bf16) kv_scatter_kernel<bf16><<<M, 256, 0, e->es>>>((const bf16*)e->QKV, (bf16*)kc, (bf16*)vc, M, d, 64, e->ctx_max);
@@ -639,6 +653,92 @@ extern "C" int vx_batch_prefill(vx_engine* e, int32_t slot, const int64_t* text,
   if (!e) return fail(VX_ERR_ARG, "null engine");
   if (slot < 0 || slot >= e->bmax) return fail(VX_ERR_ARG, "slot %d outside [0, max_batch=%d)", slot, e->bmax);
   return prefill_impl(e, slot, text, S, prompt_cb0, P, stream);
+}
+
+// All slots' prefills as ONE pass over the concatenated rows (segment z = slot z, starts at a multiple of 64 rows):
+// the GEMMs see sum(M_z) rows instead of 32 separate ~270-row problems, attention runs per segment with each
+// segment's own prefix mask, K/V go straight to each slot's cache.  Same results as vx_batch_prefill per slot up
+// to the GEMM kernel the dispatcher picks for the larger row count.
+static int ensure_rows(vx_engine* e, size_t rows, size_t audio_rows, size_t text_rows);
+static void launch_ln_batch(float* x, const float* part, int kgroups, const float* pbias, const float* gamma, const float* beta,
+                            bf16* h, int B, int d, hipStream_t s);
+template <int EPI> static int launch_bgemm(const BgemmArgs& a, hipStream_t s);
+
+extern "C" int vx_batch_prefill_all(vx_engine* e, int32_t n, const int64_t* const* text, const int32_t* S,
+                                    const int64_t* const* prompt_cb0, const int32_t* P, void* stream) {
+  if (!e || !text || !S || !prompt_cb0 || !P) return fail(VX_ERR_ARG, "null argument");
+  if (!e->finalized) return fail(VX_ERR_STATE, "weights not finalized");
+  if (n < 1 || n > e->bmax) return fail(VX_ERR_ARG, "n %d outside [1, max_batch=%d]", n, e->bmax);
+  if (!e->bf16 || !use_mfma(e)) return fail(VX_ERR_UNSUPPORTED, "vx_batch_prefill_all needs the bf16 MFMA row kernels");
+  const vx_config& c = e->cfg;
+  const int bos = c.prepend_bos ? 1 : 0, d = c.d_model;
+  std::vector<int> start(n), len(n), tlen(n);
+  size_t rows = 0;
+  int maxlen = 0;
+  for (int b = 0; b < n; ++b) {
+    if (!text[b] || (!prompt_cb0[b] && P[b] > 0)) return fail(VX_ERR_ARG, "null argument (utterance %d)", b);
+    if (S[b] <= 0 || P[b] < 0) return fail(VX_ERR_ARG, "S must be > 0 (valle.py:991), P >= 0");
+    const int A = bos + P[b];
+    if (S[b] > c.max_text || A + 1 > c.max_audio) return fail(VX_ERR_CAPACITY, "S=%d / P=%d exceed capacity", S[b], P[b]);
+    if (A == 0) return fail(VX_ERR_ARG, "empty audio prefix needs prepend_bos");
+    start[b] = (int)rows; len[b] = S[b] + A; tlen[b] = S[b];
+    rows += (size_t)((len[b] + 63) / 64) * 64;
+    if (len[b] > maxlen) maxlen = len[b];
+  }
+  HIPC(hipSetDevice(c.device));
+  VXC(ensure_rows(e, rows, e->cap_audio, e->cap_text));
+  VXC(sync_in(e, stream));
+  HIPC(hipEventRecord(e->ev_t[0], e->es));
+  HIPC(hipMemcpyAsync(e->d_seg_start, start.data(), n * sizeof(int), hipMemcpyHostToDevice, e->es));
+  HIPC(hipMemcpyAsync(e->d_seg_len, len.data(), n * sizeof(int), hipMemcpyHostToDevice, e->es));
+  HIPC(hipMemcpyAsync(e->d_seg_text, tlen.data(), n * sizeof(int), hipMemcpyHostToDevice, e->es));
+  HIPC(hipMemsetAsync(e->X, 0, rows * (size_t)d * 4, e->es));  // padding rows must stay finite (they feed V^T columns)
+  static const long long bos_id = NUM_AUDIO_TOKENS + 1;  // valle.py:1006-1007
+  for (int b = 0; b < n; ++b) {
+    const int A = bos + P[b];
+    long long* it = e->bp_text + (size_t)b * c.max_text;
+    long long* ia = e->bp_audio + (size_t)b * (c.max_audio + 1);
+    HIPC(hipMemcpyAsync(it, text[b], (size_t)S[b] * 8, hipMemcpyDefault, e->es));
+    if (bos) HIPC(hipMemcpyAsync(ia, &bos_id, 8, hipMemcpyHostToDevice, e->es));
+    if (P[b]) HIPC(hipMemcpyAsync(ia + bos, prompt_cb0[b], (size_t)P[b] * 8, hipMemcpyDefault, e->es));
+    float* xb = e->X + (size_t)start[b] * d;
+    embed_pos_kernel<<<S[b], 256, 0, e->es>>>(it, 1, 0, W<float>(e, "ar_text_embedding.word_embeddings.weight"), 512, d,
+                                              W<float>(e, "ar_text_position.alpha"), e->pe_ar, 0, xb, S[b]);
+    embed_pos_kernel<<<A, 256, 0, e->es>>>(ia, 1, 0, W<float>(e, "ar_audio_embedding.word_embeddings.weight"), 1025 + bos, d,
+                                           W<float>(e, "ar_audio_position.alpha"), e->pe_ar, 0, xb + (size_t)S[b] * d, A);
+  }
+  e->nseg = n; e->max_seg_len = maxlen; e->seg_text_on = true;
+  int rc = run_stack(e, e->ar_l, (int)rows, d, c.nhead, 0, -1, true);
+  e->nseg = 0; e->seg_text_on = false;
+  VXC(rc);
+  // decode state as of "pass 0 computed", last row of every segment = the slot's current activation
+  for (int b = 0; b < n; ++b) {
+    HIPC(hipMemcpyAsync(e->bx + (size_t)b * d, e->X + (size_t)(start[b] + len[b] - 1) * d, (size_t)d * 4, hipMemcpyDeviceToDevice, e->es));
+    ArState& st = e->h_bst[b];
+    memset(&st, 0, sizeof st);
+    st.S = S[b]; st.bos = bos; st.P = P[b]; st.row = len[b] - 1; st.pass = 0;
+    st.temperature = 1.0f; st.max_new = -1;
+  }
+  HIPC(hipMemcpyAsync(e->bst, e->h_bst, (size_t)n * sizeof(ArState), hipMemcpyHostToDevice, e->es));
+  // first logits of every slot: final LayerNorm + head, as at the end of a batched step
+  launch_ln_batch(e->bx, nullptr, 0, nullptr, W<float>(e, "ar_decoder.norm.weight"), W<float>(e, "ar_decoder.norm.bias"), e->bh, n, d, e->es);
+  BgemmArgs hgm{};
+  hgm.st = e->bst; hgm.B = n;
+  hgm.A = e->bh; hgm.W = W<bf16>(e, "ar_predict_layer.weight"); hgm.N = AR_VOCAB; hgm.K = d; hgm.kgroups = 1;
+  hgm.logits = e->blogits; hgm.logits_stride = LOGITS_CUR;
+  VXC(launch_bgemm<BE_LOGITS>(hgm, e->es));
+  HIPC(hipGetLastError());
+  HIPC(hipEventRecord(e->ev_t[1], e->es));
+  HIPC(hipStreamSynchronize(e->es));  // the staging state is reused by decode
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, e->ev_t[0], e->ev_t[1]));
+  e->t_prefill = ms;
+  for (int b = 0; b < n; ++b) {
+    e->bS[b] = S[b]; e->bP[b] = P[b]; e->bbos[b] = bos;
+    e->bprefilled[b] = true; e->bngen[b] = 0; e->breason[b] = 0;
+  }
+  VXC(sync_out(e, stream));
+  return VX_OK;
 }
 
 // One decode step: sample from the newest logits, append, run the 12-layer stack on the new
@@ -1048,7 +1148,11 @@ extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const i
 static int ensure_rows(vx_engine* e, size_t rows, size_t audio_rows, size_t text_rows) {
   const vx_config& c = e->cfg;
   const size_t dmax = c.d_model > c.nar_d_model ? c.d_model : c.nar_d_model;
-  if (rows <= (size_t)e->n_max) return VX_OK;
+  if (rows <= (size_t)e->n_max && audio_rows <= e->cap_audio && text_rows <= e->cap_text) return VX_OK;
+  if (rows < (size_t)e->n_max) rows = e->n_max;
+  if (audio_rows < e->cap_audio) audio_rows = e->cap_audio;
+  if (text_rows < e->cap_text) text_rows = e->cap_text;
+  e->cap_audio = audio_rows; e->cap_text = text_rows;
   HIPC(hipStreamSynchronize(e->es));
   auto regrow = [&](void** p, size_t bytes) -> int {
     for (auto& q : e->allocs) if (q == *p) { (void)hipFree(q); q = nullptr; }
@@ -1104,7 +1208,7 @@ extern "C" int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_
   VXC(ensure_rows(e, rows, arows, srows));
   VXC(sync_in(e, stream));
   HIPC(hipEventRecord(e->ev_t[4], e->es));
-  if (!e->d_seg_start) {
+  if (!e->d_seg_start) {  // engines created with max_batch == 1 may still batch their NAR stages
     HIPC(hipMalloc((void**)&e->d_seg_start, BMAX * sizeof(int)));
     HIPC(hipMalloc((void**)&e->d_seg_len, BMAX * sizeof(int)));
     e->allocs.push_back(e->d_seg_start); e->allocs.push_back(e->d_seg_len);

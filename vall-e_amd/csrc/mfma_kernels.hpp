@@ -293,8 +293,10 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const bf16* __restrict__ A, 
 //    lane-linear, so the bank swizzle is applied to the SOURCE address and again on the read (guide rule 21).
 //  * K is consumed in stages of 32 (rows of 64 B), FOUR LDS buffers of 32 KB: while stage t is multiplied, stages
 //    t+1..t+3 are in flight.  hipcc would drain LDS-DMA with vmcnt(0) at every __syncthreads(), so the loop uses a
-//    counted `s_waitcnt vmcnt(4)` (= the youngest stage stays in flight) + raw s_barrier; the loads past the
-//    end of K are clamped, not skipped, so the count is the same in every iteration.
+//    counted `s_waitcnt vmcnt(4)` (= the youngest stage stays in flight) + raw s_barrier.
+//  * Persistent: one workgroup per CU walks its tiles, and the stage stream runs on across tile boundaries, so the
+//    next tile's first stages land while the current tile's accumulators are written out (256 KB per tile: at
+//    K = 1024 the output write is a third of the tile's time if nothing overlaps it).
 //  * Chunk swizzle for 64-byte rows: slot = chunk ^ ((row >> 2) & 3): the 16 rows of a ds_read_b128 lane group
 //    land on 16 distinct 16-byte slots of the 256-byte bank row.
 //  * The MFMA is issued as W-fragment x A-fragment, so the accumulator has m on the lane and 4 consecutive n in
@@ -304,40 +306,47 @@ typedef float f32x4v_t __attribute__((ext_vector_type(4)));
 template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                       const float* __restrict__ bias, void* __restrict__ Cv, int M, int N,
-                                                      int K, bf16* __restrict__ vt, int vt_n0, int vt_ld, int ntn) {
+                                                      int K, bf16* __restrict__ vt, int vt_n0, int vt_ld, int ntn,
+                                                      int ntiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [4 stages][A 16 KB | W 16 KB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 15, g = lane >> 4;
-  // XCD-aware tile order: blocks with equal blockIdx % 8 (one XCD under round-robin placement; speed only) walk a
-  // contiguous run of tiles, n fastest, so concurrent neighbours share A rows / W rows in that XCD's L2
-  const int nblk = gridDim.x;
-  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-  const int q8 = nblk >> 3, r8 = nblk & 7;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-  const int mt = tile / ntn, nt = tile - mt * ntn;
-  const int m0 = mt * 256, n0 = nt * 256;
-
-  f32x4v_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+  // Persistent workgroups: workgroup b multiplies tiles v = b, b + G, b + 2G, ... (G = gridDim.x, a multiple of 8
+  // unless there are fewer tiles than CUs).  XCD-aware order: virtual blocks with equal v % 8 (one XCD under
+  // round-robin placement; speed only) walk a contiguous run of tiles, n fastest, so concurrent neighbours share
+  // A rows / W rows in that XCD's L2.
+  const int G = gridDim.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  auto tile_of = [&](int v) {
+    const int xcd = v & 7, loc = v >> 3;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  };
+  const int cnt = (ntiles - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup (>= 1)
 
   // one stage = 2048 16-byte slots (A: 1024, W: 1024), 4 per thread; slot q -> row q>>2, position q&3 holds
   // source chunk (q&3) ^ ((row>>2)&3)
   const int q0 = tid, q1 = tid + 512;
   const int rowa0 = q0 >> 2, rowa1 = q1 >> 2;
   const int ca0 = ((q0 & 3) ^ ((rowa0 >> 2) & 3)) * 8, ca1 = ((q1 & 3) ^ ((rowa1 >> 2) & 3)) * 8;
-  const bf16* srcA0 = A + (size_t)min(m0 + rowa0, M - 1) * K + ca0;
-  const bf16* srcA1 = A + (size_t)min(m0 + rowa1, M - 1) * K + ca1;
-  const bf16* srcW0 = W + (size_t)min(n0 + rowa0, N - 1) * K + ca0;
-  const bf16* srcW1 = W + (size_t)min(n0 + rowa1, N - 1) * K + ca1;
   const int d0 = (q0 - lane) * 16, d1 = (q1 - lane) * 16;  // wave-uniform LDS slot of lane 0
-  const int kmax = K - 32;
-  auto stage = [&](int buf, int k0) {
-    k0 = min(k0, kmax);
-    unsigned char* base = lds + buf * 32768;
+  const int nk = K / 32;
+
+  // ---- load side: ONE continuous stream of stages over all tiles of this workgroup, 3 stages ahead of the
+  // multiply side, so the first stages of tile i+1 arrive while tile i finishes and writes its output
+  const bf16 *srcA0, *srcA1, *srcW0, *srcW1;
+  int l_ord = 0, l_k = 0, l_slot = 0;
+  auto set_load_tile = [&](int ord) {
+    const int tile = tile_of((int)blockIdx.x + min(ord, cnt - 1) * G);  // past the end: re-read the last tile (never used)
+    const int mt = tile / ntn, nt = tile - mt * ntn;
+    srcA0 = A + (size_t)min(mt * 256 + rowa0, M - 1) * K + ca0;
+    srcA1 = A + (size_t)min(mt * 256 + rowa1, M - 1) * K + ca1;
+    srcW0 = W + (size_t)min(nt * 256 + rowa0, N - 1) * K + ca0;
+    srcW1 = W + (size_t)min(nt * 256 + rowa1, N - 1) * K + ca1;
+  };
+  auto stage = [&]() {
+    unsigned char* base = lds + (l_slot & 3) * 32768;
+    const int k0 = l_k * 32;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA0 + k0),
                                      (__attribute__((address_space(3))) void*)(base + d0), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA1 + k0),
@@ -346,15 +355,16 @@ __global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A
                                      (__attribute__((address_space(3))) void*)(base + 16384 + d0), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW1 + k0),
                                      (__attribute__((address_space(3))) void*)(base + 16384 + d1), 16, 0, 0);
+    ++l_slot;
+    if (++l_k == nk) { l_k = 0; set_load_tile(++l_ord); }
   };
 
-  const int nk = K / 32;
   // fragments of one stage: 4 W + 8 A ds_read_b128 per lane.  Two register sets: the reads of stage t+1 are issued
-  // right before the MFMAs of stage t, so the LDS phase of one stage overlaps the matrix phase of the previous one
-  // (both waves of a SIMD otherwise run their LDS and MFMA phases in lockstep and the phases add up).
+  // among the MFMAs of stage t, so the LDS phase of one stage overlaps the matrix phase of the previous one.
+  f32x4v_t acc[8][4];
   bf16x8_t fbA[4], faA[8], fbB[4], faB[8];
-  auto lread = [&](int buf, bf16x8_t (&fb)[4], bf16x8_t (&fa)[8]) {
-    const unsigned char* ba = lds + buf * 32768;
+  auto lread = [&](int slot, bf16x8_t (&fb)[4], bf16x8_t (&fa)[8]) {
+    const unsigned char* ba = lds + (slot & 3) * 32768;
     const unsigned char* bw = ba + 16384;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -373,14 +383,6 @@ __global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
   };
-  // iteration t: [issue stage t+3] [read fragments of stage t+1] [MFMAs of stage t] [vmcnt(4): stage t+2 landed] [barrier]
-  // LDS buffer (t+3)&3 was last read (as stage t-1) in iteration t-2: two barriers ago.
-  stage(0, 0);
-  stage(1, 32);
-  stage(2, 64);
-  asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // stages 0 and 1 landed everywhere
-  lread(0, fbA, faA);
-  int t = 0;
   // issue order inside one half-iteration: the 4 LDS-DMA loads and the 12 fragment reads of the NEXT stage are
   // spread between the 32 MFMAs of the current one (1 memory instruction per 2 MFMAs) instead of being bunched in
   // front of them, so the LDS and matrix pipes run concurrently within a wave too
@@ -396,57 +398,94 @@ __global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     }
   };
-  for (; t + 2 <= nk; t += 2) {
-    stage((t + 3) & 3, (t + 3) * 32);
-    lread((t + 1) & 3, fbB, faB);
-    mm(fbA, faA);
-    interleave();
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    stage((t + 4) & 3, (t + 4) * 32);
-    lread((t + 2) & 3, fbA, faA);
-    mm(fbB, faB);
-    interleave();
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-  }
-  if (t < nk) mm(fbA, faA);  // odd stage count
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail stages
 
-  // epilogue: acc[i][j][v] = C[m = m0 + wm*128 + i*16 + r][n = n0 + wn*64 + j*16 + 4g + v]
+  // Stage s of the stream lives in ring slot s & 3.  Half-iteration on stage s: [issue stage s+3] [read fragments of
+  // stage s+1] [MFMAs of stage s] [vmcnt(4): stage s+2 landed; only stage s+3 may still be in flight] [barrier].
+  // Slot (s+3)&3 was last read (as stage s-1) in the half-iteration of stage s-2: two barriers ago.
+  // hipcc would drain LDS-DMA with vmcnt(0) at every __syncthreads(), hence the counted wait + raw s_barrier.  The
+  // epilogue's stores retire in order ahead of younger loads, so the first wait of the next tile also covers them.
+  // Start-time stagger.  All tiles take the same time, so without it every CU reaches its epilogue at the same
+  // moment: HBM sits idle during the K loops and is the only thing running during the epilogues (256 CUs x 256 KB).
+  // Workgroups that have one tile fewer than the busiest ones start up to 3/4 of a tile late (free: they still
+  // finish first); with equal counts and >= 3 tiles each, everyone is spread over 4 phases (costs < 1 tile once,
+  // saves the exposed epilogue on every tile).  One tick of wall_clock64() is 10 ns.
+  {
+    const int cmax = (ntiles + G - 1) / G, rem = ntiles % G;
+    int phase = 0;
+    if (rem != 0 && cmax >= 2) phase = (int)blockIdx.x >= rem ? 1 + (int)(blockIdx.x >> 3) % 3 : 0;
+    else if (rem == 0 && cmax >= 3) phase = (int)(blockIdx.x >> 3) & 3;
+    if (phase) {
+      const unsigned long long ticks = (unsigned long long)phase * (unsigned)(nk * 20 + 100), t0 = wall_clock64();
+      while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  set_load_tile(0);
+  stage();
+  stage();
+  stage();
+  asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // stages 0 and 1 landed everywhere
+  lread(0, fbA, faA);
+  int c_slot = 0;
+  for (int ord = 0; ord < cnt; ++ord) {
+    const int tile = tile_of((int)blockIdx.x + ord * G);
+    const int mt = tile / ntn, nt = tile - mt * ntn;
+    const int m0 = mt * 256, n0 = nt * 256;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int nb = n0 + wn * 64 + j * 16 + 4 * g;  // N % 256 == 0: always in range
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (EPI != GE_PLAIN) bv = *reinterpret_cast<const float4*>(bias + nb);
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wm * 128 + i * 16 + r;
-      float x[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
-      if (EPI == GE_RELU) {
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nk; t += 2) {  // nk is even (K % 64 == 0)
+      stage();
+      lread(c_slot + 1, fbB, faB);
+      mm(fbA, faA);
+      interleave();
+      asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      stage();
+      lread(c_slot + 2, fbA, faA);
+      mm(fbB, faB);
+      interleave();
+      asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      c_slot += 2;
+    }
+
+    // epilogue: acc[i][j][v] = C[m = m0 + wm*128 + i*16 + r][n = n0 + wn*64 + j*16 + 4g + v]
 #pragma unroll
-        for (int v = 0; v < 4; ++v) x[v] = fmaxf(x[v], 0.f);
-      }
-      if (m < M) {
-        if (OUT_F32) {
-          float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (size_t)m * N + nb);
-          if (EPI == GE_RESID) {
-            const float4 o = *cp;
-            *cp = make_float4(o.x + x[0], o.y + x[1], o.z + x[2], o.w + x[3]);
+    for (int j = 0; j < 4; ++j) {
+      const int nb = n0 + wn * 64 + j * 16 + 4 * g;  // N % 256 == 0: always in range
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (EPI != GE_PLAIN) bv = *reinterpret_cast<const float4*>(bias + nb);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + r;
+        float x[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+        if (EPI == GE_RELU) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) x[v] = fmaxf(x[v], 0.f);
+        }
+        if (m < M) {
+          if (OUT_F32) {
+            float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (size_t)m * N + nb);
+            if (EPI == GE_RESID) {
+              const float4 o = *cp;
+              *cp = make_float4(o.x + x[0], o.y + x[1], o.z + x[2], o.w + x[3]);
+            } else {
+              *cp = make_float4(x[0], x[1], x[2], x[3]);
+            }
           } else {
-            *cp = make_float4(x[0], x[1], x[2], x[3]);
-          }
-        } else {
-          union { bf16 e[4]; uint2 u; } pk;
+            union { bf16 e[4]; uint2 u; } pk;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) pk.e[v] = (bf16)x[v];
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(Cv) + (size_t)m * N + nb) = pk.u;
-          if (vt != nullptr && nb >= vt_n0) {
+            for (int v = 0; v < 4; ++v) pk.e[v] = (bf16)x[v];
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(Cv) + (size_t)m * N + nb) = pk.u;
+            if (vt != nullptr && nb >= vt_n0) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) vt[(size_t)(nb + v - vt_n0) * vt_ld + m] = pk.e[v];
+              for (int v = 0; v < 4; ++v) vt[(size_t)(nb + v - vt_n0) * vt_ld + m] = pk.e[v];
+            }
           }
         }
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stages issued past the last tile
 }
 
 static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* bias, void* C, int M, int N, int K,
@@ -467,8 +506,15 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
   // 1 / 2 force one or the other (A/B runs)
   static const int alg = [] { const char* v = getenv("VX_GEMM_ALG"); return v ? atoi(v) : 0; }();
   const long long tiles64 = (long long)((M + 63) / 64) * (N / 64);
-  if (alg == 3 || (alg == 0 && N % 256 == 0 && K % 32 == 0 && K >= 128 && M >= 4096)) {  // enough 256^2 tiles for several per CU
+  if ((alg == 3 || (alg == 0 && M >= 4096)) && N % 256 == 0 && K >= 128) {  // K % 64 == 0 checked above  // enough 256^2 tiles for several per CU
     const int ntn = N / 256, ntm = (M + 255) / 256;
+    static const int ncu = [] {
+      int dev = 0, cu = 256;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+      return cu > 0 ? cu : 256;
+    }();
+    const int grid256 = ntn * ntm < ncu ? ntn * ntm : ncu;  // one persistent workgroup per CU (128 KB of LDS each)
 #define M2(E, F)                                                                                                         \
   do {                                                                                                                  \
     static bool attr_done = false;                                                                                      \
@@ -476,7 +522,7 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
       (void)hipFuncSetAttribute((const void*)mfma256_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);  \
       attr_done = true;                                                                                                 \
     }                                                                                                                   \
-    mfma256_kernel<E, F><<<ntn * ntm, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn);                   \
+    mfma256_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);          \
   } while (0)
     if (N % 256 == 0) {
       if (epi == GE_RESID) M2(GE_RESID, true);
@@ -544,6 +590,8 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
 }
 
 // ---- flash attention over rows (NAR stages: no mask; AR prefill: the reference's prefix mask) ----
+// seg_start != nullptr: the rows are a concatenation of utterances (batched NAR / batched prefill), blockIdx.z
+// picks the segment; seg_text (optional) holds each segment's text length for the prefix mask.
 // One wave = 32 queries, workgroup = NW waves sharing 64-key K / V^T tiles in LDS (double-buffered).
 // Orientation (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand"):
 //   S^T[key][query] = K . Q^T     A = K rows from LDS, B = Q rows (registers, pre-scaled by 1/8, exact)
@@ -561,13 +609,15 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void mfma_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
                                                             bf16* __restrict__ out, int M, int vt_ld, int d,
                                                             int text_len, const int* __restrict__ seg_start,
-                                                            const int* __restrict__ seg_len) {
+                                                            const int* __restrict__ seg_len,
+                                                            const int* __restrict__ seg_text) {
   constexpr int HD = 64, NT = NW * 64;
   // batched NAR: segment z of a concatenated row buffer (starts are multiples of 64 rows, so the 16-byte K / V^T
   // tile loads stay aligned); single sequence: seg_start == nullptr
   if (seg_start != nullptr) {
     const int r0 = seg_start[blockIdx.z];
     M = seg_len[blockIdx.z];
+    if (seg_text != nullptr) text_len = seg_text[blockIdx.z];  // batched prefill: every utterance has its own text length
     if ((int)blockIdx.x * 32 * NW >= M) return;
     qkv += (size_t)r0 * 3 * d;
     out += (size_t)r0 * d;
@@ -726,11 +776,12 @@ __global__ __launch_bounds__(256) void vt_from_qkv_kernel(const bf16* __restrict
 
 static inline int mfma_attn_dispatch(const bf16* qkv, const bf16* vt, int vt_ld, bf16* out, int M, int d, int H,
                                      int text_len, hipStream_t s, const int* seg_start = nullptr,
-                                     const int* seg_len = nullptr, int nseg = 1, int max_seg_len = 0) {
+                                     const int* seg_len = nullptr, int nseg = 1, int max_seg_len = 0,
+                                     const int* seg_text = nullptr) {
   constexpr int NW = 2;
   const int rows = seg_start ? max_seg_len : M;
   dim3 grid((rows + 32 * NW - 1) / (32 * NW), H, seg_start ? nseg : 1);
-  mfma_attn_kernel<NW><<<grid, NW * 64, 0, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len);
+  mfma_attn_kernel<NW><<<grid, NW * 64, 0, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
   return 0;
 }
 

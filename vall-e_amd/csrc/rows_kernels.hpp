@@ -276,6 +276,26 @@ __global__ __launch_bounds__(256) void kv_scatter_kernel(const T* __restrict__ q
   }
 }
 
+// Batched prefill: row j of segment z (rows seg_start[z] + j of the concatenated buffer) -> position j of slot z's
+// cache.  grid = (max segment length, segments).
+template <typename T>
+__global__ __launch_bounds__(256) void kv_scatter_seg_kernel(const T* __restrict__ qkv, T* __restrict__ kv_layer,
+                                                             size_t slot_stride, size_t v_offset,
+                                                             const int* __restrict__ seg_start,
+                                                             const int* __restrict__ seg_len, int d, int hd, int ctx_max) {
+  const int j = blockIdx.x, z = blockIdx.y;
+  if (j >= seg_len[z]) return;
+  const size_t r = (size_t)seg_start[z] + j;
+  T* kc = kv_layer + (size_t)z * slot_stride;
+  T* vc = kc + v_offset;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    const int h = i / hd, c = i - h * hd;
+    const size_t dst = ((size_t)h * ctx_max + j) * hd + c;
+    kc[dst] = qkv[r * 3 * d + d + i];
+    vc[dst] = qkv[r * 3 * d + 2 * d + i];
+  }
+}
+
 // samples[t] = argmax(logits[t]) (first max wins, torch.argmax valle.py:1130); also written into
 // column `col` of the (T, Q) int64 code matrix (valle.py:1136-1137).
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, int N, int rows,

@@ -54,6 +54,8 @@ _SIGS = {
     "vx_ar_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vx_nar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "vx_batch_prefill": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "vx_batch_prefill_all": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_int32), C.c_void_p]),
     "vx_batch_decode": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(VxDecodeParams), C.c_void_p]),
     "vx_batch_result": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vx_nar_batch": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 7 + [C.c_void_p]),
@@ -133,6 +135,7 @@ class Engine:
                   (VX_FLAG_SIMPLE_ROWS if simple_rows else 0)
         c.max_batch = int(max_batch)
         self.max_text, self.max_audio, self.trace_logits, self.max_batch = max_text, max_audio, trace_logits, int(max_batch)
+        self.mfma_rows = c.precision == VX_PREC_BF16 and not simple_rows
         h = C.c_void_p()
         _check(self.lib.vx_create(C.byref(c), C.byref(h)))
         self.h = h
@@ -214,6 +217,17 @@ class Engine:
         text = text.to(torch.int64).contiguous()
         prompt_cb0 = prompt_cb0.to(torch.int64).contiguous()
         _check(self.lib.vx_batch_prefill(self.h, slot, _ptr(text), text.numel(), _ptr(prompt_cb0), prompt_cb0.numel(), stream))
+
+    def batch_prefill_all(self, texts, prompts_cb0, stream=None):
+        """Slots 0..n-1 prefilled in one pass over the concatenated rows (bf16 engines)."""
+        n = len(texts)
+        texts = [t.to(torch.int64).contiguous() for t in texts]
+        proms = [p.to(torch.int64).contiguous() for p in prompts_cb0]
+        tp = (C.c_void_p * n)(*[_ptr(t) for t in texts])
+        pp = (C.c_void_p * n)(*[_ptr(p) for p in proms])
+        S = (C.c_int32 * n)(*[t.numel() for t in texts])
+        P = (C.c_int32 * n)(*[p.numel() for p in proms])
+        _check(self.lib.vx_batch_prefill_all(self.h, n, tp, S, pp, P, stream))
 
     def batch_decode(self, n_slots: int, top_k=-100, temperature=1.0, seeds=None, exp_noise=None, forced=None,
                      max_new_tokens=-1, stream=None):

@@ -168,7 +168,8 @@ class VALLE:
 
 
     @torch.no_grad()
-    def inference_batch(self, utterances, top_k: int = -100, temperature: float = 1.0, seeds=None, batched_nar: bool = True):
+    def inference_batch(self, utterances, top_k: int = -100, temperature: float = 1.0, seeds=None, batched_nar: bool = True,
+                        batched_prefill: bool = True):
         """Engine extension (BASELINE configs[2]): ``utterances`` = list of (x, x_lens, y[, enroll_x_lens]) as for
         ``inference``; up to ``max_batch`` of them advance together, one shared weight stream per AR step, each with
         its own KV cache / sampler / stop rule; the NAR stages then run per utterance.  Returns a list of (1,T_i,Q)."""
@@ -186,7 +187,10 @@ class VALLE:
                     raise RuntimeError("x must be one unpadded sequence per utterance")
                 if int(x.min()) < 0 or int(x.max()) >= NUM_TEXT_TOKENS or int(y.min()) < 0 or int(y[..., :Q].max()) >= NUM_AUDIO_TOKENS:
                     raise IndexError("index out of range in self")
-                eng.batch_prefill(b, x[0], y[0, :, 0].contiguous())
+                if not (batched_prefill and eng.mfma_rows):
+                    eng.batch_prefill(b, x[0], y[0, :, 0].contiguous())
+            if batched_prefill and eng.mfma_rows:  # one pass over the concatenated rows of the whole group
+                eng.batch_prefill_all([u[0][0] for u in group], [u[2][0, :, 0].contiguous() for u in group])
             sd = [int(torch.randint(0, 2**62, (1,))) for _ in group] if seeds is None else list(seeds[g0 : g0 + len(group)])
             eng.batch_decode(len(group), top_k=top_k, temperature=temperature, seeds=sd)
             todo = []  # (index, text_nar, prompts, tokens) of the utterances that go through the NAR stages
