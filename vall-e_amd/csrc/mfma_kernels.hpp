@@ -17,8 +17,10 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 // 128x128x64 tile, 4 waves as 2(M) x 2(N), each wave 64x64 = 2x2 MFMA tiles of 32x32.
 // LDS: double-buffered [128 rows][64 bf16] images of A and W (128-byte rows), 16-byte chunks
-// XOR-swizzled by (row & 7) so the 16 rows a ds_read_b128 lane group touches fall on 16
-// distinct 16-byte slots of the 256-byte bank row (T2).  Global->register->LDS staging with
+// XOR-swizzled by ((row >> 1) & 7) so the 16 rows a ds_read_b128 lane group touches fall on 16
+// distinct 16-byte slots of the 256-byte bank row (T2).  The lane groups of ds_read_b128 are NOT 16 consecutive
+// lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...): `row & 7` looks right on paper and measures 2-way
+// (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE); tests/lds_conflicts.py checks a swizzle against the groups.  Global->register->LDS staging with
 // the next tile's global loads issued before the current tile's MFMAs (T14 split).
 template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = tid + i * 256, row = q >> 3, c = q & 7;
-      const int off = row * 128 + ((c ^ (row & 7)) << 4);
+      const int off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
       *reinterpret_cast<uint4*>(ba + off) = ra[S][i];
       *reinterpret_cast<uint4*>(bw + off) = rw[S][i];
     }
@@ -76,9 +78,9 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = wm * 64 + i * 32 + r;
-        fa[i] = *reinterpret_cast<const bf16x8_t*>(ba + row * 128 + (((ks * 2 + h) ^ (row & 7)) << 4));
+        fa[i] = *reinterpret_cast<const bf16x8_t*>(ba + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4));
         const int col = wn * 64 + i * 32 + r;
-        fb[i] = *reinterpret_cast<const bf16x8_t*>(bw + col * 128 + (((ks * 2 + h) ^ (col & 7)) << 4));
+        fb[i] = *reinterpret_cast<const bf16x8_t*>(bw + col * 128 + (((ks * 2 + h) ^ ((col >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const bf16* __restrict__ A, 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int q = lane + i * 64, row = q >> 3, c = q & 7;
-        const int off = row * 128 + ((c ^ (row & 7)) << 4);
+        const int off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
         *reinterpret_cast<uint4*>(ba + off) = ra[S][i];
         *reinterpret_cast<uint4*>(ba + 8192 + off) = rw[S][i];
       }
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const bf16* __restrict__ A, 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int row = i * 32 + r;
-          const int off = row * 128 + (((ks * 2 + h) ^ (row & 7)) << 4);
+          const int off = row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4);
           fa[i] = *reinterpret_cast<const bf16x8_t*>(ba + off);
           fb[i] = *reinterpret_cast<const bf16x8_t*>(bw + off);
         }
@@ -297,8 +299,9 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const bf16* __restrict__ A, 
 //  * Persistent: one workgroup per CU walks its tiles, and the stage stream runs on across tile boundaries, so the
 //    next tile's first stages land while the current tile's accumulators are written out (256 KB per tile: at
 //    K = 1024 the output write is a third of the tile's time if nothing overlaps it).
-//  * Chunk swizzle for 64-byte rows: slot = chunk ^ ((row >> 2) & 3): the 16 rows of a ds_read_b128 lane group
-//    land on 16 distinct 16-byte slots of the 256-byte bank row.
+//  * Chunk swizzle for 64-byte rows: slot = chunk ^ ((0 - (row >> 2)) & 3): the 16 rows of a ds_read_b128 lane group
+//    ({0-3,12-15,20-27}, ...: rows 0-3 / 12-15 with one chunk, rows 4-11 with the next) land on 16 distinct
+//    16-byte slots of the 256-byte bank row; the obvious (row >> 2) & 3 is 2-way on these groups (measured).
 //  * The MFMA is issued as W-fragment x A-fragment, so the accumulator has m on the lane and 4 consecutive n in
 //    its registers: the epilogue stores 8 / 16 bytes per lane instead of 4 x 2-byte pieces.
 typedef float f32x4v_t __attribute__((ext_vector_type(4)));
@@ -325,10 +328,10 @@ __global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A
   const int cnt = (ntiles - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup (>= 1)
 
   // one stage = 2048 16-byte slots (A: 1024, W: 1024), 4 per thread; slot q -> row q>>2, position q&3 holds
-  // source chunk (q&3) ^ ((row>>2)&3)
+  // source chunk (q&3) ^ ((-(row>>2))&3)
   const int q0 = tid, q1 = tid + 512;
   const int rowa0 = q0 >> 2, rowa1 = q1 >> 2;
-  const int ca0 = ((q0 & 3) ^ ((rowa0 >> 2) & 3)) * 8, ca1 = ((q1 & 3) ^ ((rowa1 >> 2) & 3)) * 8;
+  const int ca0 = ((q0 & 3) ^ ((0 - (rowa0 >> 2)) & 3)) * 8, ca1 = ((q1 & 3) ^ ((0 - (rowa1 >> 2)) & 3)) * 8;
   const int d0 = (q0 - lane) * 16, d1 = (q1 - lane) * 16;  // wave-uniform LDS slot of lane 0
   const int nk = K / 32;
 
@@ -369,12 +372,12 @@ __global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = wn * 64 + j * 16 + r;
-      fb[j] = *reinterpret_cast<const bf16x8_t*>(bw + row * 64 + ((g ^ ((row >> 2) & 3)) << 4));
+      fb[j] = *reinterpret_cast<const bf16x8_t*>(bw + row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4));
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = wm * 128 + i * 16 + r;
-      fa[i] = *reinterpret_cast<const bf16x8_t*>(ba + row * 64 + ((g ^ ((row >> 2) & 3)) << 4));
+      fa[i] = *reinterpret_cast<const bf16x8_t*>(ba + row * 64 + ((g ^ ((0 - (row >> 2)) & 3)) << 4));
     }
   };
   auto mm = [&](const bf16x8_t (&fb)[4], const bf16x8_t (&fa)[8]) {
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(NW * 64) void mfma_attn_kernel(const bf16* __restri
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       const int q = tid + i * NT, row = q >> 3, c = q & 7;
-      const int off = row * 128 + ((c ^ (row & 7)) << 4);
+      const int off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
       *reinterpret_cast<uint4*>(&lds[buf][0][off]) = rk[i];
       *reinterpret_cast<uint4*>(&lds[buf][1][off]) = rv[i];
     }
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(NW * 64) void mfma_attn_kernel(const bf16* __restri
       const int krow = sub * 32 + r;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + krow * 128 + (((ks * 2 + hh) ^ (krow & 7)) << 4));
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + krow * 128 + (((ks * 2 + hh) ^ ((krow >> 1) & 7)) << 4));
         accS[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], accS[sub], 0, 0, 0);
       }
     }
@@ -742,8 +745,8 @@ __global__ __launch_bounds__(NW * 64) void mfma_attn_kernel(const bf16* __restri
           const int vrow = t * 32 + r;
           const unsigned char* rowp = vb + vrow * 128 + 8 * hh;
           union { bf16x8_t v8; uint2 u[2]; } vf;
-          vf.u[0] = *reinterpret_cast<const uint2*>(rowp + ((c0 ^ (vrow & 7)) << 4));
-          vf.u[1] = *reinterpret_cast<const uint2*>(rowp + (((c0 + 1) ^ (vrow & 7)) << 4));
+          vf.u[0] = *reinterpret_cast<const uint2*>(rowp + ((c0 ^ ((vrow >> 1) & 7)) << 4));
+          vf.u[1] = *reinterpret_cast<const uint2*>(rowp + (((c0 + 1) ^ ((vrow >> 1) & 7)) << 4));
           accO[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v8, pf[sub][s2], accO[t], 0, 0, 0);
         }
       }
