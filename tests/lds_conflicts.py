@@ -33,3 +33,8 @@ if __name__ == "__main__":
     for name, f in (("row&7", lambda row: row & 7), ("(row>>1)&7", lambda row: (row >> 1) & 7)):
         worst = max(cycles(lambda l: (l & 31) * 128 + ((c ^ f(l & 31)) << 4) + 8 * (l >> 5), 8, G64) for c in range(8))
         print("128-B rows, V^T b64 read, swizzle", name, "->", worst, "cycles (ideal 2)")
+    # 128-B rows, 16-row fragments (16x16x32): lane -> row = l&15, chunk (4ks + (l>>4)) ^ f(row)
+    for name, f in (("row&7", lambda row: row & 7), ("(row>>1)&7", lambda row: (row >> 1) & 7), ("row&7 ^ 4*(row>>3&1)", lambda row: (row & 7) ^ (4 * ((row >> 3) & 1))),
+                    ("((row>>1)&3)|((row&1)<<2)", lambda row: ((row >> 1) & 3) | ((row & 1) << 2))):
+        worst = max(cycles(lambda l: (l & 15) * 128 + ((((4 * ks) + (l >> 4)) ^ f(l & 15)) << 4), 16, G128) for ks in range(2))
+        print("128-B rows, 16-row fragment, swizzle", name, "->", worst, "cycles (ideal 4)")

@@ -407,21 +407,6 @@ __global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A
   // Slot (s+3)&3 was last read (as stage s-1) in the half-iteration of stage s-2: two barriers ago.
   // hipcc would drain LDS-DMA with vmcnt(0) at every __syncthreads(), hence the counted wait + raw s_barrier.  The
   // epilogue's stores retire in order ahead of younger loads, so the first wait of the next tile also covers them.
-  // Start-time stagger.  All tiles take the same time, so without it every CU reaches its epilogue at the same
-  // moment: HBM sits idle during the K loops and is the only thing running during the epilogues (256 CUs x 256 KB).
-  // Workgroups that have one tile fewer than the busiest ones start up to 3/4 of a tile late (free: they still
-  // finish first); with equal counts and >= 3 tiles each, everyone is spread over 4 phases (costs < 1 tile once,
-  // saves the exposed epilogue on every tile).  One tick of wall_clock64() is 10 ns.
-  {
-    const int cmax = (ntiles + G - 1) / G, rem = ntiles % G;
-    int phase = 0;
-    if (rem != 0 && cmax >= 2) phase = (int)blockIdx.x >= rem ? 1 + (int)(blockIdx.x >> 3) % 3 : 0;
-    else if (rem == 0 && cmax >= 3) phase = (int)(blockIdx.x >> 3) & 3;
-    if (phase) {
-      const unsigned long long ticks = (unsigned long long)phase * (unsigned)(nk * 20 + 100), t0 = wall_clock64();
-      while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
-    }
-  }
   set_load_tile(0);
   stage();
   stage();
