@@ -55,7 +55,9 @@ enum vx_stop_reason {
 enum vx_flags {
   VX_FLAG_TRACE_LOGITS = 1, /* keep the (1025,) AR logits of every pass (parity tests) */
   VX_FLAG_NO_GRAPH = 2,     /* launch the AR step kernel by kernel instead of as a hipGraph */
-  VX_FLAG_SIMPLE_ROWS = 4   /* bf16 mode: use the scalar-FMA row kernels instead of MFMA (A/B checks) */
+  VX_FLAG_SIMPLE_ROWS = 4,  /* bf16 mode: use the scalar-FMA row kernels instead of MFMA (A/B checks) */
+  VX_FLAG_POST_NORM = 8     /* norm_first=False (valle.py:60, transformer.py:303-308): x = norm(x + block(x)), no final
+                               encoder norms; batch-1 path only (max_batch must be <= 1) */
 };
 
 /* Mirrors VALLE.__init__ (valle.py:727-760) / get_model (models/__init__.py:112-124). */

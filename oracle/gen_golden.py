@@ -46,6 +46,10 @@ CASES = {
     "tiny_q2_unshared": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=1, num_quantizers=2, share_embedding=False), 5, 12, 1, 1.0, None, None, (0, 3)),
     # nar_scale_factor = 0.5 (valle_test.py:131: "params.scale_factor = 0.5"): NAR stack of half width / heads / depth
     "tiny_scale05": (dict(decoder_dim=256, nhead=4, num_decoder_layers=4, prefix_mode=1, scale_factor=0.5), 6, 12, 4, 1.0, 11, None, (0, 9)),
+    # norm_first=False, the ordering the reference's own smoke test builds (valle_test.py:105: "params.norm_first = False")
+    "tiny_postnorm": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=1, norm_first=False), 7, 14, 4, 1.0, 21, None, (0, 5)),
+    "tiny_postnorm_mode0": (dict(decoder_dim=128, nhead=2, num_decoder_layers=3, prefix_mode=0, norm_first=False), 6, 10, 1, 1.0, None, None, (0, 5)),
+    "cfg0_postnorm": (dict(decoder_dim=256, nhead=4, num_decoder_layers=4, prefix_mode=1, norm_first=False), 10, 60, 10, 1.0, 4321, None, (0, 1, 80, 160)),
     # BASELINE.json configs[1]: d=1024 nhead=16 L=12, top-k 10, S=47 -> 753 tokens x 8 codebooks
     "cfg1_topk10": (dict(decoder_dim=1024, nhead=16, num_decoder_layers=12, prefix_mode=1), 47, 225, 10, 1.0, 1234, None, (0, 1, 376, 752)),
 }
@@ -85,7 +89,7 @@ def run_case(name: str):
 
     # pin the oracle before writing anything
     m = vo.OracleModel(sd, cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, cfg.prefix_mode,
-                       cfg.prepend_bos, cfg.num_quantizers, cfg.scale_factor)
+                       cfg.prepend_bos, cfg.num_quantizers, cfg.scale_factor, cfg.norm_first)
     tr = {}
     oc = vo.inference_cached(m, x, x_lens, y, enroll_x_lens, top_k, temp, noise, trace=tr)
     assert torch.equal(oc, codes), f"{name}: cached oracle differs from the reference"
@@ -101,6 +105,7 @@ def run_case(name: str):
         cfg=np.array([cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, cfg.prefix_mode,
                       int(cfg.prepend_bos), cfg.num_quantizers, int(cfg.share_embedding)], dtype=np.int32),
         weight_seed=np.int32(0), input_seed=np.int32(1), scale_factor=np.float32(cfg.scale_factor),
+        norm_first=np.int32(int(cfg.norm_first)),
         x=x.numpy().astype(np.int16), x_lens=x_lens.numpy(), y=y.numpy().astype(np.int16),
         enroll=np.int32(-1 if enroll is None else enroll),
         top_k=np.int32(top_k), temperature=np.float32(temp),

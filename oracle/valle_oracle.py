@@ -108,11 +108,16 @@ class _Layer:
         return layer_norm(x, w, b)
 
 
-def encoder_layer(L: _Layer, x, nhead, mask, stage_emb=None):
-    """Pre-norm branch of TransformerEncoderLayer.forward, transformer.py:296-302, 315-334."""
-    a, kv = self_attention(L.norm(0, x, stage_emb), L.in_w, L.in_b, L.out_w, L.out_b, nhead, mask)
-    x = x + a
-    x = x + F.linear(F.relu(F.linear(L.norm(1, x, stage_emb), L.w1, L.b1)), L.w2, L.b2)
+def encoder_layer(L: _Layer, x, nhead, mask, stage_emb=None, norm_first: bool = True):
+    """TransformerEncoderLayer.forward: pre-norm branch transformer.py:296-302, post-norm branch 303-308; blocks 315-334."""
+    if norm_first:
+        a, kv = self_attention(L.norm(0, x, stage_emb), L.in_w, L.in_b, L.out_w, L.out_b, nhead, mask)
+        x = x + a
+        x = x + F.linear(F.relu(F.linear(L.norm(1, x, stage_emb), L.w1, L.b1)), L.w2, L.b2)
+        return x, kv
+    a, kv = self_attention(x, L.in_w, L.in_b, L.out_w, L.out_b, nhead, mask)
+    x = L.norm(0, x + a, stage_emb)
+    x = L.norm(1, x + F.linear(F.relu(F.linear(x, L.w1, L.b1)), L.w2, L.b2), stage_emb)
     return x, kv
 
 
@@ -152,8 +157,9 @@ def topk_sampling(logits: torch.Tensor, top_k: int, temperature: float, exp_nois
 class OracleModel:
     def __init__(self, sd: Dict[str, torch.Tensor], d_model: int, nhead: int, num_layers: int,
                  prefix_mode: int = 0, prepend_bos: bool = False, num_quantizers: int = 8,
-                 nar_scale_factor: float = 1.0):
+                 nar_scale_factor: float = 1.0, norm_first: bool = True):
         self.sd = sd
+        self.norm_first = norm_first
         self.d, self.nhead, self.L = d_model, nhead, num_layers
         self.dn = int(d_model * nar_scale_factor)
         self.nar_nhead = int(nhead * nar_scale_factor)
@@ -175,7 +181,12 @@ class OracleModel:
     def ar_stack(self, xy: torch.Tensor, mask) -> torch.Tensor:  # valle.py:1035-1038
         x = xy
         for L in self.ar_layers:
-            x, _ = encoder_layer(L, x, self.nhead, mask)
+            x, _ = encoder_layer(L, x, self.nhead, mask, None, self.norm_first)
+        return self.ar_final_norm(x)
+
+    def ar_final_norm(self, x: torch.Tensor) -> torch.Tensor:  # norm=LayerNorm(d) if norm_first else None (valle.py:151)
+        if not self.norm_first:
+            return x
         return layer_norm(x, self.sd["ar_decoder.norm.weight"], self.sd["ar_decoder.norm.bias"])
 
     def ar_logits(self, h_last: torch.Tensor) -> torch.Tensor:  # valle.py:1039
@@ -186,7 +197,9 @@ class OracleModel:
         e = self.sd[f"nar_stage_embeddings.{stage}.word_embeddings.weight"]
         x = xy
         for L in self.nar_layers:
-            x, _ = encoder_layer(L, x, self.nar_nhead, None, e)
+            x, _ = encoder_layer(L, x, self.nar_nhead, None, e, self.norm_first)
+        if not self.norm_first:  # valle.py:242-246
+            return x
         g = lambda n: self.sd[f"nar_decoder.norm.{n}"]
         return ada_layer_norm(x, e, g("project_layer.weight"), g("project_layer.bias"), g("norm.weight"), g("norm.bias"))
 
@@ -294,11 +307,10 @@ class ArCache:
         mask = ar_mask(S, yy.shape[0])
         self.k, self.v = [], []
         for L in m.ar_layers:
-            x, (k, v) = encoder_layer(L, x, m.nhead, mask)
+            x, (k, v) = encoder_layer(L, x, m.nhead, mask, None, m.norm_first)
             self.k.append(k)
             self.v.append(v)
-        h = layer_norm(x[-1:], m.sd["ar_decoder.norm.weight"], m.sd["ar_decoder.norm.bias"])
-        return m.ar_logits(h)
+        return m.ar_logits(m.ar_final_norm(x[-1:]))
 
     def step(self, token: torch.Tensor) -> torch.Tensor:
         """token: (1,) int64 — the audio token appended at audio position ``n_audio``."""
@@ -308,7 +320,7 @@ class ArCache:
         d, H = m.d, m.nhead
         hd = d // H
         for li, L in enumerate(m.ar_layers):
-            hN = L.norm(0, x, None)
+            hN = L.norm(0, x, None) if m.norm_first else x
             qkv = F.linear(hN, L.in_w, L.in_b)
             q, k, v = qkv.chunk(3, dim=-1)
             q = q.reshape(1, H, hd).transpose(0, 1)
@@ -318,9 +330,12 @@ class ArCache:
             a = torch.matmul(F.softmax(s, dim=-1), self.v[li])  # (H,1,hd)
             a = a.transpose(0, 1).reshape(1, d)
             x = x + F.linear(a, L.out_w, L.out_b)
-            x = x + F.linear(F.relu(F.linear(L.norm(1, x, None), L.w1, L.b1)), L.w2, L.b2)
-        h = layer_norm(x, m.sd["ar_decoder.norm.weight"], m.sd["ar_decoder.norm.bias"])
-        return m.ar_logits(h)
+            if m.norm_first:
+                x = x + F.linear(F.relu(F.linear(L.norm(1, x, None), L.w1, L.b1)), L.w2, L.b2)
+            else:
+                x = L.norm(0, x, None)
+                x = L.norm(1, x + F.linear(F.relu(F.linear(x, L.w1, L.b1)), L.w2, L.b2), None)
+        return m.ar_logits(m.ar_final_norm(x))
 
 
 @torch.no_grad()

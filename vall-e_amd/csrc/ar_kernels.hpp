@@ -31,6 +31,8 @@ struct GemvArgs {
   const float* beta;
   const float* part;   // PRO_ATTN: (nhead, ATT_NSPLIT, ATT_PSTRIDE) split-KV partials
   float* y;            // output vector / residual stream / logits base
+  const float* res;    // EPI_RESID: residual source (null: y itself).  Post-norm layers add to the NORMALISED stream
+  float* xnorm_out;    // PRO_LN: if set, workgroup 0 / wave 0 also stores LN(x) here (post-norm: the next residual base)
   int N, K;
   int pro, epi;
   // EPI_QKV
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   {
     const int rc = min(g * RPW + min(lane, RPW - 1), N - 1);
     if (has_bias) e_bias = a.bias[rc];
-    if (has_res) e_res = a.y[rc];
+    if (has_res) e_res = (a.res ? a.res : a.y)[rc];
   }
   int st_row = 0, st_pass = 0, st_trace = 0, st_done = 0;
   if (a.st) { st_row = a.st->row; st_pass = a.st->pass; st_trace = a.st->trace_logits; st_done = a.st->done; }
@@ -184,6 +186,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
           xr[c][4 * j] = kok[c] ? o0 : 0.f; xr[c][4 * j + 1] = kok[c] ? o1 : 0.f;
           xr[c][4 * j + 2] = kok[c] ? o2 : 0.f; xr[c][4 * j + 3] = kok[c] ? o3 : 0.f;
         }
+      if (a.xnorm_out != nullptr && blockIdx.x == 0 && wave == 0) {  // wave-uniform; stores only, after every load was issued
+#pragma unroll
+        for (int c = 0; c < KCH; ++c)
+          if (kok[c]) {
+#pragma unroll
+            for (int j = 0; j < V4; ++j)
+              *reinterpret_cast<float4*>(a.xnorm_out + (c * 64 + lane) * VEC + 4 * j) =
+                  make_float4(xr[c][4 * j], xr[c][4 * j + 1], xr[c][4 * j + 2], xr[c][4 * j + 3]);
+          }
+      }
     }
   }
 
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     {
       const int rc = min(g * RPW + min(lane, RPW - 1), N - 1);
       if (has_bias) e_bias = a.bias[rc];
-      if (has_res) e_res = a.y[rc];
+      if (has_res) e_res = (a.res ? a.res : a.y)[rc];
     }
     issue(g);
   }

@@ -81,7 +81,7 @@ struct vx_engine {
   bool pe_ar_set = false, pe_nar_set = false;
   // AR buffers
   int ctx_max = 0;
-  float *ar_x = nullptr, *ar_q = nullptr, *ar_part = nullptr, *ar_f = nullptr, *ar_logits = nullptr;
+  float *ar_x = nullptr, *ar_xn = nullptr, *ar_q = nullptr, *ar_part = nullptr, *ar_f = nullptr, *ar_logits = nullptr;
   void* kv = nullptr;  // [L][2][H][ctx_max][hd]
   ArState* d_st = nullptr;
   ArState* h_st = nullptr;  // pinned: [0] staging, [1..2] poll slots
@@ -143,6 +143,7 @@ static bool is_matrix_key(const std::string& k) {
 
 // The reference's state_dict layout (valle.py:85-259); mirrored by valle_amd/weights.py.
 static void add_encoder_keys(vx_engine* e, const std::string& pre, int d, int L, bool adaptive) {
+  const bool post = e->cfg.flags & VX_FLAG_POST_NORM;  // norm=... if norm_first else None (valle.py:151, 242-246)
   auto add = [&](const std::string& k, std::vector<int64_t> s) {
     Tensor t; t.shape = s; t.numel = 1; for (auto v : s) t.numel *= (size_t)v;
     t.low = e->bf16 && is_matrix_key(k);
@@ -164,7 +165,7 @@ static void add_encoder_keys(vx_engine* e, const std::string& pre, int d, int L,
     add(p + ".linear2.weight", {d, 4 * d}); add(p + ".linear2.bias", {d});
     norm(p + ".norm1"); norm(p + ".norm2");
   }
-  norm(pre + ".norm");
+  if (!post) norm(pre + ".norm");
 }
 
 static void build_key_table(vx_engine* e) {
@@ -220,6 +221,7 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
     return fail(VX_ERR_UNSUPPORTED, "d_model must be a multiple of 64 and <= 1024");
   if (c.max_text <= 0 || c.max_audio <= 0) return fail(VX_ERR_ARG, "capacities must be positive");
   if (c.precision != VX_PREC_F32 && c.precision != VX_PREC_BF16) return fail(VX_ERR_ARG, "bad precision");
+  if ((c.flags & VX_FLAG_POST_NORM) && c.max_batch > 1) return fail(VX_ERR_UNSUPPORTED, "post-norm models run on the batch-1 path only");
   if (c.max_batch < 0 || c.max_batch > BMAX) return fail(VX_ERR_ARG, "max_batch must be 0..%d", BMAX);
   if (c.max_batch > 1 && (c.precision != VX_PREC_BF16 || c.d_model % 128))
     return fail(VX_ERR_UNSUPPORTED, "batched decode needs bf16 precision and d_model % 128 == 0");
@@ -251,6 +253,7 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   // AR
   VXC(dalloc_t(e, &e->ar_x, d));
   VXC(dalloc_t(e, &e->ar_q, d));
+  VXC(dalloc_t(e, &e->ar_xn, d));  // post-norm decode: the normalised residual stream
   VXC(dalloc_t(e, &e->ar_part, (size_t)H * ATT_NSPLIT * ATT_PSTRIDE));
   VXC(dalloc_t(e, &e->ar_f, 4 * (size_t)d));
   const size_t nlog = (c.flags & VX_FLAG_TRACE_LOGITS) ? (size_t)c.max_audio + 2 : 1;
@@ -422,7 +425,8 @@ extern "C" int vx_finalize_weights(vx_engine* e) {
     const int dn = c.nar_d_model, Ln = c.nar_num_layers;
     for (int s = 0; s < c.num_quantizers - 1; ++s) {
       const float* emb = W<float>(e, "nar_stage_embeddings." + std::to_string(s) + ".word_embeddings.weight");
-      for (int site = 0; site < 2 * Ln + 1; ++site) {
+      const int nsite = 2 * Ln + ((c.flags & VX_FLAG_POST_NORM) ? 0 : 1);  // post-norm: no final AdaLN
+      for (int site = 0; site < nsite; ++site) {
         std::string p = site == 2 * Ln ? std::string("nar_decoder.norm")
                                        : "nar_decoder.layers." + std::to_string(site / 2) + (site % 2 ? ".norm2" : ".norm1");
         project_vec_kernel<<<(2 * dn + 3) / 4, 256, 0, e->es>>>(W<float>(e, p + ".project_layer.weight"),
@@ -501,9 +505,15 @@ static int gemm_rows(vx_engine* e, const void* A, const void* Wt, const float* b
 }
 
 static int ln_rows(vx_engine* e, const float* x, const float* g, const float* b, const float* aw, const float* ab,
-                   void* out, int rows, int d) {
-  if (e->bf16) layernorm_rows_kernel<bf16><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (bf16*)out, rows, d);
-  else layernorm_rows_kernel<float><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (float*)out, rows, d);
+                   void* out, int rows, int d, float* xout = nullptr) {
+  if (e->bf16) layernorm_rows_kernel<bf16><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (bf16*)out, rows, d, xout);
+  else layernorm_rows_kernel<float><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (float*)out, rows, d, xout);
+  return VX_OK;
+}
+// rows of the fp32 residual stream -> the GEMM operand type, no normalisation (input of a post-norm stack)
+static int cast_rows(vx_engine* e, const float* x, void* out, size_t n) {
+  if (e->bf16) convert_kernel<bf16><<<1024, 256, 0, e->es>>>(x, (bf16*)out, n);
+  else convert_kernel<float><<<1024, 256, 0, e->es>>>(x, (float*)out, n);
   return VX_OK;
 }
 
@@ -525,6 +535,7 @@ static int attn_rows(vx_engine* e, const void* qkv, void* out, int M, int d, int
 static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int d, int H, int text_len, int ada_stage,
                      bool fill_cache, char* kv_base = nullptr) {
   if (kv_base == nullptr) kv_base = (char*)e->kv;
+  const bool post = e->cfg.flags & VX_FLAG_POST_NORM;
   const size_t kv_layer = (size_t)2 * H * e->ctx_max * 64 * e->esz;
   for (size_t li = 0; li < layers.size(); ++li) {
     const LayerW& l = layers[li];
@@ -533,7 +544,10 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
       aw1 = ada_vec(e, ada_stage, 2 * (int)li); ab1 = aw1 + d;
       aw2 = ada_vec(e, ada_stage, 2 * (int)li + 1); ab2 = aw2 + d;
     }
-    VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d));
+    // pre-norm (transformer.py:296-302): Hn = norm1(x).  post-norm (303-308): the block reads x itself; Hn already
+    // holds it in operand precision from the previous layer's norm2 (layer 0: cast here)
+    if (!post) VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d));
+    else if (li == 0) VXC(cast_rows(e, e->X, e->Hn, (size_t)M * d));
     VXC(gemm_rows(e, e->Hn, l.in_w, l.in_b, e->QKV, M, 3 * d, d, GE_BIAS, false, use_mfma(e)));
     if (fill_cache && e->nseg > 0) {  // batched prefill: segment z -> slot z
       const size_t kvl = (size_t)2 * H * e->ctx_max * 64;  // elements per layer
@@ -547,9 +561,11 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
     }
     VXC(attn_rows(e, e->QKV, e->ATT, M, d, H, text_len));
     VXC(gemm_rows(e, e->ATT, l.out_w, l.out_b, e->X, M, d, d, GE_RESID, true));
-    VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn, M, d));
+    if (!post) VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn, M, d));
+    else VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d, e->X));  // x = norm1(x + sa(x))
     VXC(gemm_rows(e, e->Hn, l.w1, l.b1, e->FF, M, 4 * d, d, GE_RELU, false));
     VXC(gemm_rows(e, e->FF, l.w2, l.b2, e->X, M, d, 4 * d, GE_RESID, true));
+    if (post) VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn, M, d, e->X));  // x = norm2(x + ff(x))
   }
   HIPC(hipGetLastError());
   return VX_OK;
@@ -571,18 +587,22 @@ static int sync_out(vx_engine* e, void* stream) {
 }
 
 // ------------------------------------------------------------------------------ AR
+// prefilled: x is a row of the prefill stack's output.  Pre-norm: the final LayerNorm is fused here (valle.py:1035-1039).
+// Post-norm: there is no final norm; a prefill row is already norm2'd, the decode step's x still needs the last
+// layer's norm2 (fused here instead).
 static int enqueue_head(vx_engine* e, hipStream_t s, const float* x = nullptr, float* logits = nullptr,
-                        const ArState* st = nullptr) {
+                        const ArState* st = nullptr, bool prefilled = false) {
   const vx_config& c = e->cfg;
+  const bool post = c.flags & VX_FLAG_POST_NORM;
   GemvArgs a{};
   a.W = W<void>(e, "ar_predict_layer.weight");
   a.bias = nullptr;
   a.x = x ? x : e->ar_x;
-  a.gamma = W<float>(e, "ar_decoder.norm.weight");
-  a.beta = W<float>(e, "ar_decoder.norm.bias");
+  a.gamma = post ? e->ar_l.back().n2_g : W<float>(e, "ar_decoder.norm.weight");
+  a.beta = post ? e->ar_l.back().n2_b : W<float>(e, "ar_decoder.norm.bias");
   a.y = logits ? logits : e->ar_logits;
   a.N = AR_VOCAB; a.K = c.d_model;
-  a.pro = PRO_LN; a.epi = EPI_LOGITS;
+  a.pro = (post && prefilled) ? PRO_COPY : PRO_LN; a.epi = EPI_LOGITS;
   a.st = st ? st : e->d_st;
   return launch_gemv(e->bf16, a, e->num_cu, s);
 }
@@ -624,7 +644,7 @@ static int prefill_impl(vx_engine* e, int slot, const int64_t* text, int32_t S, 
   st.temperature = 1.0f; st.max_new = -1;
   st.trace_logits = (slot < 0 && (c.flags & VX_FLAG_TRACE_LOGITS)) ? 1 : 0;
   HIPC(hipMemcpyAsync(st_dst, &st, sizeof st, hipMemcpyHostToDevice, e->es));
-  VXC(enqueue_head(e, e->es, x_dst, lg_dst, st_dst));
+  VXC(enqueue_head(e, e->es, x_dst, lg_dst, st_dst, true));
   HIPC(hipGetLastError());
   HIPC(hipEventRecord(e->ev_t[1], e->es));
   HIPC(hipStreamSynchronize(e->es));  // the staging state is reused by decode
@@ -747,6 +767,7 @@ extern "C" int vx_batch_prefill_all(vx_engine* e, int32_t n, const int64_t* cons
 static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
   const vx_config& c = e->cfg;
   const int d = c.d_model, H = c.nhead, hd = 64;
+  const bool post = c.flags & VX_FLAG_POST_NORM;
   SampleArgs sa{};
   sa.logits = e->ar_logits; sa.V = AR_VOCAB; sa.st = e->d_st;
   sa.tokens = e->d_tokens; sa.sampled = e->d_sampled; sa.argmaxes = e->d_argmax;
@@ -765,6 +786,14 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     // qkv = in_proj(LN1(x)); k,v appended to the cache (transformer.py:297-301)
     a.W = l.in_w; a.bias = l.in_b; a.x = e->ar_x; a.gamma = l.n1_g; a.beta = l.n1_b;
     a.N = 3 * d; a.K = d; a.pro = PRO_LN; a.epi = EPI_QKV; a.q = e->ar_q; a.kcache = kc; a.vcache = vc;
+    // post-norm (transformer.py:303-308): ar_x holds the raw sum x + block(x) of the previous sub-layer and the norm that
+    // follows it is fused into the NEXT kernel's prologue, which also leaves the normalised vector in ar_xn as the
+    // base of the next residual add.  Layer 0 reads the fresh embedding as is.
+    const float* res = nullptr;  // residual base of this layer's attention block (null: ar_x itself)
+    if (post) {
+      if (li == 0) { a.pro = PRO_COPY; }
+      else { a.gamma = e->ar_l[li - 1].n2_g; a.beta = e->ar_l[li - 1].n2_b; a.xnorm_out = e->ar_xn; res = e->ar_xn; }
+    }
     VXC(launch_gemv(e->bf16, a, e->num_cu, s));
     if (e->bf16) attn_decode_kernel<bf16, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale);
     else attn_decode_kernel<float, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale);
@@ -772,17 +801,20 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     GemvArgs o{};
     o.st = e->d_st; o.hd = hd; o.nhead = H;
     o.W = l.out_w; o.bias = l.out_b; o.part = e->ar_part; o.y = e->ar_x; o.N = d; o.K = d; o.pro = PRO_ATTN; o.epi = EPI_RESID;
+    o.res = res;
     VXC(launch_gemv(e->bf16, o, e->num_cu, s));
     // f = relu(linear1(LN2(x)))
     GemvArgs f{};
     f.st = e->d_st;
     f.W = l.w1; f.bias = l.b1; f.x = e->ar_x; f.gamma = l.n2_g; f.beta = l.n2_b; f.y = e->ar_f;
     f.N = 4 * d; f.K = d; f.pro = PRO_LN; f.epi = EPI_RELU;
+    if (post) { f.gamma = l.n1_g; f.beta = l.n1_b; f.xnorm_out = e->ar_xn; }  // x = norm1(x + sa(x)), kept in ar_xn
     VXC(launch_gemv(e->bf16, f, e->num_cu, s));
     // x += linear2(f)
     GemvArgs g{};
     g.st = e->d_st;
     g.W = l.w2; g.bias = l.b2; g.x = e->ar_f; g.y = e->ar_x; g.N = d; g.K = 4 * d; g.pro = PRO_COPY; g.epi = EPI_RESID;
+    if (post) g.res = e->ar_xn;  // raw sum norm1(..) + ff(..); its norm2 runs in the next layer's (or the head's) prologue
     VXC(launch_gemv(e->bf16, g, e->num_cu, s));
   }
   VXC(enqueue_head(e, s));
@@ -1119,9 +1151,13 @@ extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const i
       add_pos_kernel<<<A, 256, 0, e->es>>>(e->yemb, dn, a_aud, e->pe_nar, 0, e->X + (size_t)S2 * dn, A);
       VXC(run_stack(e, e->nar_l, N, dn, c.nar_nhead, -1, i, false));
       // final AdaLN + predict layer on the T generated rows only (valle.py:1128)
-      const float* fw = ada_vec(e, i, 2 * c.nar_num_layers);
-      VXC(ln_rows(e, e->X + (size_t)(S2 + P) * dn, W<float>(e, "nar_decoder.norm.norm.weight"),
-                  W<float>(e, "nar_decoder.norm.norm.bias"), fw, fw + dn, e->Hn, T, dn));
+      if (c.flags & VX_FLAG_POST_NORM) {  // no final norm (valle.py:242-246): the rows are already norm2'd
+        VXC(cast_rows(e, e->X + (size_t)(S2 + P) * dn, e->Hn, (size_t)T * dn));
+      } else {
+        const float* fw = ada_vec(e, i, 2 * c.nar_num_layers);
+        VXC(ln_rows(e, e->X + (size_t)(S2 + P) * dn, W<float>(e, "nar_decoder.norm.norm.weight"),
+                    W<float>(e, "nar_decoder.norm.norm.bias"), fw, fw + dn, e->Hn, T, dn));
+      }
       VXC(gemm_rows(e, e->Hn, W<void>(e, "nar_predict_layers." + std::to_string(i) + ".weight"), nullptr, e->nar_logits,
                     T, 1024, dn, GE_PLAIN, true));
       argmax_rows_kernel<<<(T + 3) / 4, 256, 0, e->es>>>(e->nar_logits, 1024, T, e->ids_samples, e->d_codes, Q, i + 1);
@@ -1244,10 +1280,15 @@ extern "C" int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_
     }
     rc = run_stack(e, e->nar_l, (int)rows, dn, c.nar_nhead, -1, i, false);
     if (rc != VX_OK) break;
-    const float* fw = ada_vec(e, i, 2 * c.nar_num_layers);
-    for (int b = 0; b < n; ++b)  // final AdaLN on the generated rows only, compacted to [sum T][dn]
-      rc = ln_rows(e, e->X + (size_t)(start[b] + S2[b] + P[b]) * dn, W<float>(e, "nar_decoder.norm.norm.weight"),
-                   W<float>(e, "nar_decoder.norm.norm.bias"), fw, fw + dn, (bf16*)e->Hn + (size_t)toff[b] * dn, T[b], dn);
+    const bool post = c.flags & VX_FLAG_POST_NORM;
+    const float* fw = post ? nullptr : ada_vec(e, i, 2 * c.nar_num_layers);
+    for (int b = 0; b < n; ++b) {  // final AdaLN (pre-norm only) on the generated rows, compacted to [sum T][dn]
+      const float* xr = e->X + (size_t)(start[b] + S2[b] + P[b]) * dn;
+      bf16* hr = (bf16*)e->Hn + (size_t)toff[b] * dn;
+      rc = post ? cast_rows(e, xr, hr, (size_t)T[b] * dn)
+                : ln_rows(e, xr, W<float>(e, "nar_decoder.norm.norm.weight"), W<float>(e, "nar_decoder.norm.norm.bias"), fw,
+                          fw + dn, hr, T[b], dn);
+    }
     const int nseg_keep = e->nseg;
     e->nseg = 0;  // the predict GEMM below is a plain GEMM
     rc = gemm_rows(e, e->Hn, W<void>(e, "nar_predict_layers." + std::to_string(i) + ".weight"), nullptr, e->nar_logits,

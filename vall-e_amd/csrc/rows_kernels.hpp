@@ -50,11 +50,13 @@ __global__ __launch_bounds__(256) void embed_accum_kernel(const long long* __res
 // (Adaptive)LayerNorm, one wave per row: out = [w *] (LN(x) * gamma + beta) [+ b]
 // (modules/transformer.py:57-74, 93-108).  OT = float or bf16 (the GEMM A-operand type).
 template <typename OT>
-__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ ada_w,
                                                              const float* __restrict__ ada_b, OT* __restrict__ out,
-                                                             int rows, int d) {
+                                                             int rows, int d, float* xout = nullptr) {
+  // xout (post-norm layers, transformer.py:303-308): the normalised row also replaces the residual stream; it may
+  // alias x (every element is read into registers by its own lane before anything is stored)
   constexpr int MAXV = 8;  // d <= 2048
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
       OT* op = out + (size_t)r * d + k;
 #pragma unroll
       for (int j = 0; j < 4; ++j) op[j] = from_f32<OT>(o[j]);
+      if (xout != nullptr) *reinterpret_cast<float4*>(xout + (size_t)r * d + k) = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
 }

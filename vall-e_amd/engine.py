@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvallex.so")
 
 VX_PREC_F32, VX_PREC_BF16 = 0, 1
-VX_FLAG_TRACE_LOGITS, VX_FLAG_NO_GRAPH, VX_FLAG_SIMPLE_ROWS = 1, 2, 4
+VX_FLAG_TRACE_LOGITS, VX_FLAG_NO_GRAPH, VX_FLAG_SIMPLE_ROWS, VX_FLAG_POST_NORM = 1, 2, 4, 8
 STOP_REASONS = {0: "none", 1: "eos_argmax", 2: "eos_sample", 3: "length", 4: "max_new"}
 
 
@@ -132,7 +132,7 @@ class Engine:
         c.precision = {"fp32": VX_PREC_F32, "f32": VX_PREC_F32, "bf16": VX_PREC_BF16}[precision]
         c.max_text, c.max_audio, c.device = max_text, max_audio, self.device
         c.flags = (VX_FLAG_TRACE_LOGITS if trace_logits else 0) | (VX_FLAG_NO_GRAPH if no_graph else 0) | \
-                  (VX_FLAG_SIMPLE_ROWS if simple_rows else 0)
+                  (VX_FLAG_SIMPLE_ROWS if simple_rows else 0) | (0 if getattr(cfg, "norm_first", True) else VX_FLAG_POST_NORM)
         c.max_batch = int(max_batch)
         self.max_text, self.max_audio, self.trace_logits, self.max_batch = max_text, max_audio, trace_logits, int(max_batch)
         self.mfma_rows = c.precision == VX_PREC_BF16 and not simple_rows

@@ -41,8 +41,10 @@ class VALLE:
                                num_quantizers=kwargs.pop("num_quantizers", 8))
         if kwargs:
             raise TypeError(f"unexpected arguments {sorted(kwargs)}")
-        if not norm_first or add_prenet:
-            raise NotImplementedError("post-norm / prenet variants are outside the built scope (DESIGN.md §out of scope)")
+        if add_prenet:
+            raise NotImplementedError("add_prenet=True (valle.py:96-123) is outside the built scope (DESIGN.md)")
+        if not norm_first and self.engine_opts.get("max_batch", 0) > 1:
+            raise NotImplementedError("norm_first=False runs on the batch-1 path only (inference_batch needs pre-norm)")
         if self.cfg.num_quantizers > 1 and (self.cfg.nar_nhead <= 0 or self.cfg.nar_dim != 64 * self.cfg.nar_nhead):
             raise NotImplementedError("nar_scale_factor must keep the NAR head_dim at 64 (DESIGN.md)")
         self.ar_audio_prepend_bos = self.cfg.prepend_bos

@@ -24,7 +24,7 @@ import torch
 from .config import NUM_AUDIO_TOKENS, NUM_TEXT_TOKENS, ModelConfig
 
 
-def _encoder_keys(prefix: str, d: int, layers: int, adaptive: bool) -> "OrderedDict[str, Tuple[int, ...]]":
+def _encoder_keys(prefix: str, d: int, layers: int, adaptive: bool, final_norm: bool = True) -> "OrderedDict[str, Tuple[int, ...]]":
     out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     for i in range(layers):
         p = f"{prefix}.layers.{i}"
@@ -45,6 +45,8 @@ def _encoder_keys(prefix: str, d: int, layers: int, adaptive: bool) -> "OrderedD
             else:
                 out[f"{p}.{n}.weight"] = (d,)
                 out[f"{p}.{n}.bias"] = (d,)
+    if not final_norm:  # norm_first=False: the encoder has no final norm (valle.py:151, 242-246)
+        return out
     if adaptive:
         out[f"{prefix}.norm.project_layer.weight"] = (2 * d, d)
         out[f"{prefix}.norm.project_layer.bias"] = (2 * d,)
@@ -57,9 +59,9 @@ def _encoder_keys(prefix: str, d: int, layers: int, adaptive: bool) -> "OrderedD
 
 
 def expected_keys(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
-    """state_dict keys -> shapes for VALLE(norm_first=True, add_prenet=False) (valle.py:85-259).
-    372 entries at L=12 / 8 quantizers."""
-    assert cfg.norm_first and not cfg.add_prenet, "only the default pre-norm / no-prenet layout"
+    """state_dict keys -> shapes for VALLE(add_prenet=False) (valle.py:85-259).  372 entries at L=12 / 8 quantizers
+    with norm_first=True; post-norm models have no final encoder norms."""
+    assert not cfg.add_prenet, "prenets are not built"
     d, dn = cfg.decoder_dim, cfg.nar_dim
     q = cfg.num_quantizers
     k: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
@@ -68,7 +70,7 @@ def expected_keys(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     k["ar_audio_embedding.word_embeddings.weight"] = (NUM_AUDIO_TOKENS + 1 + int(cfg.prepend_bos), d)
     k["ar_text_position.alpha"] = (1,)
     k["ar_audio_position.alpha"] = (1,)
-    k.update(_encoder_keys("ar_decoder", d, cfg.num_decoder_layers, adaptive=False))
+    k.update(_encoder_keys("ar_decoder", d, cfg.num_decoder_layers, adaptive=False, final_norm=cfg.norm_first))
     k["ar_predict_layer.weight"] = (NUM_AUDIO_TOKENS + 1, d)
     if q > 1:
         k["nar_audio_embeddings.0.word_embeddings.weight"] = (NUM_AUDIO_TOKENS + 1, dn)
@@ -76,7 +78,7 @@ def expected_keys(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
             k[f"nar_audio_embeddings.{j}.word_embeddings.weight"] = (NUM_AUDIO_TOKENS, dn)
         k["nar_text_position.alpha"] = (1,)
         k["nar_audio_position.alpha"] = (1,)
-        k.update(_encoder_keys("nar_decoder", dn, cfg.nar_layers, adaptive=True))
+        k.update(_encoder_keys("nar_decoder", dn, cfg.nar_layers, adaptive=True, final_norm=cfg.norm_first))
         for j in range(q - 1):
             k[f"nar_predict_layers.{j}.weight"] = (NUM_AUDIO_TOKENS, dn)
         for j in range(q - 1):
