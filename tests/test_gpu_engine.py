@@ -102,7 +102,8 @@ def test_torch_cpu_sampling_mode_follows_global_generator():
 
 
 @pytest.mark.parametrize("name,simple", [("cfg0_topk10", False), ("cfg0_topk10", True), ("tiny_mode0", False),
-                                         ("tiny_mode2_q6", False), ("cfg1_topk10", False)])
+                                         ("tiny_mode2_q6", False), ("cfg0_postnorm", False), ("cfg0_postnorm", True),
+                                         ("cfg1_topk10", False)])
 def test_bf16_engine_teacher_forced(name, simple):
     from oracle import valle_oracle as vo
 
