@@ -56,6 +56,8 @@ enum vx_flags {
   VX_FLAG_TRACE_LOGITS = 1, /* keep the (1025,) AR logits of every pass (parity tests) */
   VX_FLAG_NO_GRAPH = 2,     /* launch the AR step kernel by kernel instead of as a hipGraph */
   VX_FLAG_SIMPLE_ROWS = 4,  /* bf16 mode: use the scalar-FMA row kernels instead of MFMA (A/B checks) */
+  VX_FLAG_PRENET = 16,      /* add_prenet=True (valle.py:96-123, 181-213): conv/BatchNorm text prenets and MLP audio
+                               prenets in front of the position embeddings, fp32; batch-1 path only */
   VX_FLAG_POST_NORM = 8     /* norm_first=False (valle.py:60, transformer.py:303-308): x = norm(x + block(x)), no final
                                encoder norms; batch-1 path only (max_batch must be <= 1) */
 };
@@ -129,6 +131,10 @@ int vx_ar_result(vx_engine* e, int64_t* tokens, int32_t capacity, int32_t* n_tok
  * trim (done by the host shim, valle.py:1068-1079); prompts: (P, Q) row-major; ar_tokens: (T,);
  * codes_out: (T, Q) int64 row-major, column 0 = ar_tokens (valle.py:1136-1137). */
 int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
+           const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream);
+/* VALLE.continual's NAR body (valle.py:1185-1236): same arguments as vx_nar.  Differs from vx_nar only for models with
+ * prenets in prefix mode 0, where continual() applies the audio position BEFORE the audio prenet (valle.py:1193-1194). */
+int vx_nar_continual(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
            const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream);
 
 /* ---- batched AR decode (BASELINE configs[2]): up to max_batch utterances ("slots") advance one token per

@@ -50,6 +50,10 @@ CASES = {
     "tiny_postnorm": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=1, norm_first=False), 7, 14, 4, 1.0, 21, None, (0, 5)),
     "tiny_postnorm_mode0": (dict(decoder_dim=128, nhead=2, num_decoder_layers=3, prefix_mode=0, norm_first=False), 6, 10, 1, 1.0, None, None, (0, 5)),
     "cfg0_postnorm": (dict(decoder_dim=256, nhead=4, num_decoder_layers=4, prefix_mode=1, norm_first=False), 10, 60, 10, 1.0, 4321, None, (0, 1, 80, 160)),
+    # add_prenet=True (valle.py:96-123; the reference's smoke test builds its models with it, valle_test.py:106)
+    "tiny_prenet": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=1, add_prenet=True), 7, 14, 4, 1.0, 31, None, (0, 5)),
+    "tiny_prenet_postnorm_mode0": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=0, add_prenet=True, norm_first=False), 6, 11, 3, 1.0, 32, None, (0, 5)),
+    "tiny_prenet_mode2_bos": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=2, add_prenet=True, prepend_bos=True, num_quantizers=7), 9, 12, 1, 1.0, None, 4, (0, 5)),
     # BASELINE.json configs[1]: d=1024 nhead=16 L=12, top-k 10, S=47 -> 753 tokens x 8 codebooks
     "cfg1_topk10": (dict(decoder_dim=1024, nhead=16, num_decoder_layers=12, prefix_mode=1), 47, 225, 10, 1.0, 1234, None, (0, 1, 376, 752)),
 }
@@ -89,7 +93,7 @@ def run_case(name: str):
 
     # pin the oracle before writing anything
     m = vo.OracleModel(sd, cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, cfg.prefix_mode,
-                       cfg.prepend_bos, cfg.num_quantizers, cfg.scale_factor, cfg.norm_first)
+                       cfg.prepend_bos, cfg.num_quantizers, cfg.scale_factor, cfg.norm_first, cfg.add_prenet)
     tr = {}
     oc = vo.inference_cached(m, x, x_lens, y, enroll_x_lens, top_k, temp, noise, trace=tr)
     assert torch.equal(oc, codes), f"{name}: cached oracle differs from the reference"
@@ -105,7 +109,7 @@ def run_case(name: str):
         cfg=np.array([cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, cfg.prefix_mode,
                       int(cfg.prepend_bos), cfg.num_quantizers, int(cfg.share_embedding)], dtype=np.int32),
         weight_seed=np.int32(0), input_seed=np.int32(1), scale_factor=np.float32(cfg.scale_factor),
-        norm_first=np.int32(int(cfg.norm_first)),
+        norm_first=np.int32(int(cfg.norm_first)), add_prenet=np.int32(int(cfg.add_prenet)),
         x=x.numpy().astype(np.int16), x_lens=x_lens.numpy(), y=y.numpy().astype(np.int16),
         enroll=np.int32(-1 if enroll is None else enroll),
         top_k=np.int32(top_k), temperature=np.float32(temp),
@@ -123,24 +127,26 @@ def run_case(name: str):
     print(f"[{name}] wrote {os.path.getsize(os.path.join(OUT, name + '.npz')) / 1024:.0f} KiB", flush=True)
 
 
-def run_continual(name: str, prefix_mode: int, S: int, T: int):
+def run_continual(name: str, prefix_mode: int, S: int, T: int, add_prenet: bool = False):
     """valle.py:1139-1238 via bin/infer.py:224-230 (--continual)."""
-    cfg = ModelConfig(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=prefix_mode)
+    cfg = ModelConfig(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=prefix_mode, add_prenet=add_prenet)
     sd = synthetic_state_dict(cfg, seed=0)
     x, x_lens, y = synthetic_inputs(S, T, 8, seed=3)
     ref = build_reference_model(cfg, sd)
     with torch.no_grad():
         codes = ref.continual(x, x_lens, y)
-    m = vo.OracleModel(sd, cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, cfg.prefix_mode, False, 8)
+    m = vo.OracleModel(sd, cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, cfg.prefix_mode, False, 8, add_prenet=add_prenet)
     assert torch.equal(vo.continual(m, x, x_lens, y), codes), f"{name}: oracle continual differs from the reference"
     print(f"[{name}] reference continual {tuple(codes.shape)}; oracle == reference", flush=True)
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"),
                         cfg=np.array([128, 2, 2, prefix_mode, 0, 8, 1], dtype=np.int32), weight_seed=np.int32(0),
+                        add_prenet=np.int32(int(add_prenet)),
                         x=x.numpy().astype(np.int16), x_lens=x_lens.numpy(), y=y.numpy().astype(np.int16),
                         codes=codes.numpy().astype(np.int16))
 
 
-CONTINUAL = {"continual_mode0": (0, 7, 41), "continual_mode1": (1, 9, 64)}
+CONTINUAL = {"continual_mode0": (0, 7, 41), "continual_mode1": (1, 9, 64),
+             "continual_prenet_mode0": (0, 6, 37, True), "continual_prenet_mode1": (1, 8, 50, True)}
 
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))

@@ -121,6 +121,25 @@ def encoder_layer(L: _Layer, x, nhead, mask, stage_emb=None, norm_first: bool = 
     return x, kv
 
 
+def text_prenet(sd, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """{ar,nar}_text_prenet in eval mode (valle.py:97-113): Transpose, 3 x [Conv1d(k=5, same), BatchNorm1d (running
+    statistics), ReLU, Dropout (inactive)], Transpose, Linear.  x (S,d) -> (S,d)."""
+    h = x.t().unsqueeze(0)  # (1,d,S)
+    for conv, bn in ((1, 2), (5, 6), (9, 10)):
+        h = F.conv1d(h, sd[f"{prefix}.{conv}.weight"], sd[f"{prefix}.{conv}.bias"], padding="same")
+        h = F.batch_norm(h, sd[f"{prefix}.{bn}.running_mean"], sd[f"{prefix}.{bn}.running_var"], sd[f"{prefix}.{bn}.weight"],
+                         sd[f"{prefix}.{bn}.bias"], training=False, eps=1e-5)
+        h = F.relu(h)
+    return F.linear(h[0].t(), sd[f"{prefix}.14.weight"], sd[f"{prefix}.14.bias"])
+
+
+def audio_prenet(sd, prefix: str, y: torch.Tensor) -> torch.Tensor:
+    """{ar,nar}_audio_prenet in eval mode (valle.py:115-123): Linear(d,256), ReLU, Linear(256,256), ReLU, Linear(256,d)."""
+    h = F.relu(F.linear(y, sd[f"{prefix}.0.weight"], sd[f"{prefix}.0.bias"]))
+    h = F.relu(F.linear(h, sd[f"{prefix}.3.weight"], sd[f"{prefix}.3.bias"]))
+    return F.linear(h, sd[f"{prefix}.6.weight"], sd[f"{prefix}.6.bias"])
+
+
 def ar_mask(S: int, A: int) -> torch.Tensor:
     """valle.py:1010, 1018-1033: text rows see text only; audio rows see all text + causal audio."""
     m = torch.zeros(S + A, S + A, dtype=torch.bool)
@@ -157,9 +176,10 @@ def topk_sampling(logits: torch.Tensor, top_k: int, temperature: float, exp_nois
 class OracleModel:
     def __init__(self, sd: Dict[str, torch.Tensor], d_model: int, nhead: int, num_layers: int,
                  prefix_mode: int = 0, prepend_bos: bool = False, num_quantizers: int = 8,
-                 nar_scale_factor: float = 1.0, norm_first: bool = True):
+                 nar_scale_factor: float = 1.0, norm_first: bool = True, add_prenet: bool = False):
         self.sd = sd
         self.norm_first = norm_first
+        self.add_prenet = add_prenet
         self.d, self.nhead, self.L = d_model, nhead, num_layers
         self.dn = int(d_model * nar_scale_factor)
         self.nar_nhead = int(nhead * nar_scale_factor)
@@ -172,10 +192,14 @@ class OracleModel:
     # -- AR pieces ---------------------------------------------------------------------------
     def ar_text(self, text: torch.Tensor) -> torch.Tensor:  # (S,) -> (S,d); valle.py:995-997
         e = F.embedding(text, self.sd["ar_text_embedding.word_embeddings.weight"])
+        if self.add_prenet:  # valle.py:996
+            e = text_prenet(self.sd, "ar_text_prenet", e)
         return add_position(e, self.sd["ar_text_position.alpha"])
 
     def ar_audio(self, y: torch.Tensor, start: int = 0) -> torch.Tensor:  # valle.py:1013-1015
         e = F.embedding(y, self.sd["ar_audio_embedding.word_embeddings.weight"])
+        if self.add_prenet:  # valle.py:1014
+            e = audio_prenet(self.sd, "ar_audio_prenet", e)
         return add_position(e, self.sd["ar_audio_position.alpha"], start)
 
     def ar_stack(self, xy: torch.Tensor, mask) -> torch.Tensor:  # valle.py:1035-1038
@@ -204,23 +228,31 @@ class OracleModel:
         return ada_layer_norm(x, e, g("project_layer.weight"), g("project_layer.bias"), g("norm.weight"), g("norm.bias"))
 
     def nar(self, text: torch.Tensor, text_len: int, prompts: torch.Tensor, y: torch.Tensor,
-            enroll_x_lens, trace: Optional[dict] = None) -> List[torch.Tensor]:
+            enroll_x_lens, trace: Optional[dict] = None, position_before_prenet: bool = False) -> List[torch.Tensor]:
         """valle.py:1059-1134.  text (S,), prompts (P,Q), y (P+T,) = prompt cb0 + AR tokens.
-        Returns the Q-1 NAR code rows, each (T,)."""
+        Returns the Q-1 NAR code rows, each (T,).  position_before_prenet: the order VALLE.continual uses in
+        prefix mode 0 (valle.py:1193-1194), the reverse of every other call site."""
         sd, P = self.sd, prompts.shape[0]
         y_emb = F.embedding(y, sd["nar_audio_embeddings.0.word_embeddings.weight"]).clone()
         if self.prefix_mode in (2, 4):  # valle.py:1068-1079
             enrolled_len = int(enroll_x_lens.max().item())
             text = torch.cat([text[:1], text[enrolled_len - 1:]])
             text_len = text_len - (enrolled_len - 2)
-        x = add_position(F.embedding(text, sd["nar_text_embedding.word_embeddings.weight"]),
-                         sd["nar_text_position.alpha"])
+        x = F.embedding(text, sd["nar_text_embedding.word_embeddings.weight"])
+        if self.add_prenet:  # valle.py:1082
+            x = text_prenet(sd, "nar_text_prenet", x)
+        x = add_position(x, sd["nar_text_position.alpha"])
         codes = []
         if self.prefix_mode != 0:  # valle.py:1110-1113
             for j in range(1, self.Q):
                 y_emb[:P] += F.embedding(prompts[:, j], sd[f"nar_audio_embeddings.{j}.word_embeddings.weight"])
         for i in range(self.Q - 1):
-            y_pos = add_position(y_emb, sd["nar_audio_position.alpha"])
+            if not self.add_prenet:
+                y_pos = add_position(y_emb, sd["nar_audio_position.alpha"])
+            elif position_before_prenet:
+                y_pos = audio_prenet(sd, "nar_audio_prenet", add_position(y_emb, sd["nar_audio_position.alpha"]))
+            else:  # valle.py:1092-1093, 1121-1122
+                y_pos = add_position(audio_prenet(sd, "nar_audio_prenet", y_emb), sd["nar_audio_position.alpha"])
             xy = torch.cat([x, y_pos], dim=0)
             h = self.nar_stack(xy, i)
             logits = F.linear(h[text_len + P:], sd[f"nar_predict_layers.{i}.weight"])
@@ -399,7 +431,7 @@ def continual(m: OracleModel, x, x_lens, y) -> torch.Tensor:
     saved = m.prefix_mode
     try:
         m.prefix_mode = 0 if saved == 0 else 1  # the NAR body only distinguishes mode 0 from the rest here
-        codes += m.nar(text, S, prompts, y[0, :, 0], None)
+        codes += m.nar(text, S, prompts, y[0, :, 0], None, position_before_prenet=(saved == 0))
     finally:
         m.prefix_mode = saved
     return torch.stack(codes, dim=-1).unsqueeze(0)

@@ -36,7 +36,8 @@ class Golden:
         self.cfg = ModelConfig(decoder_dim=c[0], nhead=c[1], num_decoder_layers=c[2], prefix_mode=c[3],
                                prepend_bos=bool(c[4]), num_quantizers=c[5], share_embedding=bool(c[6]),
                                scale_factor=float(z["scale_factor"]) if "scale_factor" in z else 1.0,
-                               norm_first=bool(int(z["norm_first"])) if "norm_first" in z else True)
+                               norm_first=bool(int(z["norm_first"])) if "norm_first" in z else True,
+                               add_prenet=bool(int(z["add_prenet"])) if "add_prenet" in z else False)
         self.weight_seed = int(z["weight_seed"])
         self.x = torch.from_numpy(z["x"].astype(np.int64))
         self.x_lens = torch.from_numpy(z["x_lens"])
@@ -66,7 +67,7 @@ class Golden:
         c = self.cfg
         return vo.OracleModel(sd if sd is not None else self.state_dict(), c.decoder_dim, c.nhead,
                               c.num_decoder_layers, c.prefix_mode, c.prepend_bos, c.num_quantizers, c.scale_factor,
-                              c.norm_first)
+                              c.norm_first, c.add_prenet)
 
 
 @pytest.fixture(scope="session")

@@ -25,7 +25,8 @@ def _model(g, precision, **kw):
     from valle_amd.models import VALLE
 
     c = g.cfg
-    m = VALLE(c.decoder_dim, c.nhead, c.num_decoder_layers, norm_first=c.norm_first, prefix_mode=c.prefix_mode, share_embedding=c.share_embedding,
+    m = VALLE(c.decoder_dim, c.nhead, c.num_decoder_layers, norm_first=c.norm_first, add_prenet=c.add_prenet, prefix_mode=c.prefix_mode,
+              share_embedding=c.share_embedding,
               nar_scale_factor=c.scale_factor, prepend_bos=c.prepend_bos, num_quantizers=c.num_quantizers, precision=precision, max_text=128,
               max_audio=1280, print_eos=False, **kw)
     m.load_state_dict(g.state_dict())

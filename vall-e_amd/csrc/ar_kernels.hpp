@@ -17,7 +17,7 @@
 namespace vx {
 
 enum GemvPro { PRO_COPY = 0, PRO_LN = 1, PRO_ATTN = 2 };
-enum GemvEpi { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU = 2, EPI_RESID = 3, EPI_QKV = 4, EPI_LOGITS = 5 };
+enum GemvEpi { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU = 2, EPI_RESID = 3, EPI_QKV = 4, EPI_LOGITS = 5, EPI_POS = 6 };  // POS: + bias + alpha * pe[audio position] (last prenet layer)
 
 constexpr int LOGITS_CUR = 1088;     // floats reserved for the newest logits row at the buffer head; trace rows follow
 constexpr int ATT_NSPLIT = 8;        // key splits per head in the decode attention
@@ -32,6 +32,8 @@ struct GemvArgs {
   const float* part;   // PRO_ATTN: (nhead, ATT_NSPLIT, ATT_PSTRIDE) split-KV partials
   float* y;            // output vector / residual stream / logits base
   const float* res;    // EPI_RESID: residual source (null: y itself).  Post-norm layers add to the NORMALISED stream
+  const float* pe;     // EPI_POS: sine table (rows, N) and its alpha (valle.py:1014-1015 with add_prenet)
+  const float* pos_alpha;
   float* xnorm_out;    // PRO_LN: if set, workgroup 0 / wave 0 also stores LN(x) here (post-norm: the next residual base)
   int N, K;
   int pro, epi;
@@ -99,8 +101,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     if (has_bias) e_bias = a.bias[rc];
     if (has_res) e_res = (a.res ? a.res : a.y)[rc];
   }
-  int st_row = 0, st_pass = 0, st_trace = 0, st_done = 0;
-  if (a.st) { st_row = a.st->row; st_pass = a.st->pass; st_trace = a.st->trace_logits; st_done = a.st->done; }
+  int st_row = 0, st_pass = 0, st_trace = 0, st_done = 0, st_S = 0;
+  if (a.st) { st_row = a.st->row; st_pass = a.st->pass; st_trace = a.st->trace_logits; st_done = a.st->done; st_S = a.st->S; }
 
   // ---- (B) weight stream of the first row group (rows/k clamped; x is zero where k >= K) ----
   uint4 w[RPW][KCH];
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       switch (a.epi) {
         case EPI_RELU: a.y[row] = fmaxf(v, 0.f); break;
         case EPI_RESID: a.y[row] = e_res + v; break;
+        case EPI_POS: a.y[row] = __fadd_rn(v, __fmul_rn(a.pos_alpha[0], a.pe[(size_t)(st_row - st_S) * N + row])); break;
         case EPI_LOGITS:  // a finished decode keeps replaying the step: leave its last logits row intact
           if (!st_done) {
             a.y[row] = v;  // fixed address: the sampling kernel's loads do not wait for the step counter

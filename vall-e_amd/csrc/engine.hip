@@ -109,6 +109,10 @@ struct vx_engine {
   std::unordered_map<int, hipGraphExec_t> bgraphs;
   int *d_seg_start = nullptr, *d_seg_len = nullptr;  // segments of the concatenated row buffer (batched NAR / prefill)
   int* d_seg_text = nullptr;                          // per-segment text length (prefix mask of a batched prefill)
+  // prenets (VX_FLAG_PRENET): scratch rows, conv weights re-laid out as [k][ci][co], decode-step vectors
+  float *pn_a = nullptr, *pn_b = nullptr, *pn_h1 = nullptr, *pn_h2 = nullptr, *pn_text = nullptr, *d_zero = nullptr;
+  float *ar_e = nullptr, *ar_h1 = nullptr, *ar_h2 = nullptr;
+  float* convT[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   bool seg_text_on = false;                           // true only while a batched prefill runs its stack
   long long *bp_text = nullptr, *bp_audio = nullptr;  // id staging of the batched prefill
   size_t cap_audio = 0, cap_text = 0;                 // rows the id / yemb / logits staging buffers hold
@@ -133,6 +137,8 @@ static int dalloc(vx_engine* e, void** p, size_t bytes) {
   return VX_OK;
 }
 template <typename T> static int dalloc_t(vx_engine* e, T** p, size_t n) { return dalloc(e, (void**)p, n * sizeof(T)); }
+
+constexpr int PRENET_H = 256;  // hidden width of the audio prenets (valle.py:116-122)
 
 static bool is_matrix_key(const std::string& k) {
   auto ends = [&](const char* s) { size_t n = strlen(s); return k.size() >= n && k.compare(k.size() - n, n, s) == 0; };
@@ -179,6 +185,21 @@ static void build_key_table(vx_engine* e) {
   add("ar_text_embedding.word_embeddings.weight", {512, d});
   add("nar_text_embedding.word_embeddings.weight", {512, dn});
   add("ar_audio_embedding.word_embeddings.weight", {1025 + (c.prepend_bos ? 1 : 0), d});
+  // prenets (valle.py:96-123, 181-213): Sequential indices as in the reference; BatchNorm's num_batches_tracked is an
+  // integer counter the forward pass never reads and is not passed through the C ABI
+  auto prenet = [&](const std::string& pre, int dd) {
+    for (int conv : {1, 5, 9}) {
+      const std::string cv = pre + "_text_prenet." + std::to_string(conv), bn = pre + "_text_prenet." + std::to_string(conv + 1);
+      add(cv + ".weight", {dd, dd, 5}); add(cv + ".bias", {dd});
+      add(bn + ".weight", {dd}); add(bn + ".bias", {dd}); add(bn + ".running_mean", {dd}); add(bn + ".running_var", {dd});
+    }
+    add(pre + "_text_prenet.14.weight", {dd, dd}); add(pre + "_text_prenet.14.bias", {dd});
+    add(pre + "_audio_prenet.0.weight", {PRENET_H, dd}); add(pre + "_audio_prenet.0.bias", {PRENET_H});
+    add(pre + "_audio_prenet.3.weight", {PRENET_H, PRENET_H}); add(pre + "_audio_prenet.3.bias", {PRENET_H});
+    add(pre + "_audio_prenet.6.weight", {dd, PRENET_H}); add(pre + "_audio_prenet.6.bias", {dd});
+  };
+  const bool pn = c.flags & VX_FLAG_PRENET;
+  if (pn) prenet("ar", d);
   add("ar_text_position.alpha", {1});
   add("ar_audio_position.alpha", {1});
   add_encoder_keys(e, "ar_decoder", d, c.num_layers, false);
@@ -186,6 +207,7 @@ static void build_key_table(vx_engine* e) {
   if (Q > 1) {
     add("nar_audio_embeddings.0.word_embeddings.weight", {1025, dn});
     for (int j = 1; j < Q; ++j) add("nar_audio_embeddings." + std::to_string(j) + ".word_embeddings.weight", {1024, dn});
+    if (pn) prenet("nar", dn);
     add("nar_text_position.alpha", {1});
     add("nar_audio_position.alpha", {1});
     add_encoder_keys(e, "nar_decoder", dn, c.nar_num_layers, true);
@@ -221,7 +243,8 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
     return fail(VX_ERR_UNSUPPORTED, "d_model must be a multiple of 64 and <= 1024");
   if (c.max_text <= 0 || c.max_audio <= 0) return fail(VX_ERR_ARG, "capacities must be positive");
   if (c.precision != VX_PREC_F32 && c.precision != VX_PREC_BF16) return fail(VX_ERR_ARG, "bad precision");
-  if ((c.flags & VX_FLAG_POST_NORM) && c.max_batch > 1) return fail(VX_ERR_UNSUPPORTED, "post-norm models run on the batch-1 path only");
+  if ((c.flags & (VX_FLAG_POST_NORM | VX_FLAG_PRENET)) && c.max_batch > 1)
+    return fail(VX_ERR_UNSUPPORTED, "post-norm / prenet models run on the batch-1 path only");
   if (c.max_batch < 0 || c.max_batch > BMAX) return fail(VX_ERR_ARG, "max_batch must be 0..%d", BMAX);
   if (c.max_batch > 1 && (c.precision != VX_PREC_BF16 || c.d_model % 128))
     return fail(VX_ERR_UNSUPPORTED, "batched decode needs bf16 precision and d_model % 128 == 0");
@@ -282,6 +305,22 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   VXC(dalloc_t(e, &e->ids_samples, (size_t)c.max_audio));
   VXC(dalloc_t(e, &e->d_codes, (size_t)c.max_audio * 8));
   e->cap_audio = c.max_audio; e->cap_text = c.max_text;
+  if (c.flags & VX_FLAG_PRENET) {
+    VXC(dalloc_t(e, &e->pn_a, n * dmax));
+    VXC(dalloc_t(e, &e->pn_b, n * dmax));
+    VXC(dalloc_t(e, &e->pn_h1, n * PRENET_H));
+    VXC(dalloc_t(e, &e->pn_h2, n * PRENET_H));
+    VXC(dalloc_t(e, &e->pn_text, (size_t)c.max_text * dmax));
+    VXC(dalloc_t(e, &e->d_zero, 4));
+    HIPC(hipMemset(e->d_zero, 0, 16));
+    VXC(dalloc_t(e, &e->ar_e, d));
+    VXC(dalloc_t(e, &e->ar_h1, PRENET_H));
+    VXC(dalloc_t(e, &e->ar_h2, PRENET_H));
+    for (int i = 0; i < 3; ++i) {
+      VXC(dalloc_t(e, &e->convT[0][i], (size_t)5 * d * d));
+      if (c.num_quantizers > 1) VXC(dalloc_t(e, &e->convT[1][i], (size_t)5 * dn * dn));
+    }
+  }
   if (c.max_batch > 1) {
     e->bmax = c.max_batch;
     e->btok_stride = c.max_audio + 2;
@@ -436,6 +475,16 @@ extern "C" int vx_finalize_weights(vx_engine* e) {
     }
     HIPC(hipGetLastError());
   }
+  if (c.flags & VX_FLAG_PRENET) {
+    for (int which = 0; which < (c.num_quantizers > 1 ? 2 : 1); ++which) {
+      const int dd = which ? c.nar_d_model : c.d_model;
+      const size_t nel = (size_t)5 * dd * dd;
+      for (int i = 0; i < 3; ++i)
+        conv_weight_relayout_kernel<<<(unsigned)((nel + 255) / 256), 256, 0, e->es>>>(
+            W<float>(e, std::string(which ? "nar" : "ar") + "_text_prenet." + std::to_string(1 + 4 * i) + ".weight"), e->convT[which][i], dd);
+    }
+    HIPC(hipGetLastError());
+  }
   HIPC(hipStreamSynchronize(e->es));
   e->finalized = true;
   return VX_OK;
@@ -510,6 +559,34 @@ static int ln_rows(vx_engine* e, const float* x, const float* g, const float* b,
   else layernorm_rows_kernel<float><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (float*)out, rows, d, xout);
   return VX_OK;
 }
+// fp32 linear layer on rows (prenets keep fp32 weights in every precision mode): C = [relu](A W^T + b)
+static int linear_rows_f32(vx_engine* e, const float* A, const float* Wt, const float* bias, float* Cm, int M, int N, int K, bool relu) {
+  return gemm_rows_t<float>(false, A, Wt, bias, Cm, M, N, K, relu ? GE_RELU : GE_BIAS, true, e->es);
+}
+// text prenet (valle.py:97-113): `in` (S, dd) raw embeddings -> `out` (S, dd); uses pn_a / pn_b as scratch (in/out may be them)
+static int text_prenet_rows(vx_engine* e, int which, const float* in, float* out, int S, int dd) {
+  const std::string pre = std::string(which ? "nar" : "ar") + "_text_prenet.";
+  const float* src = in;
+  float* bufs[2] = {e->pn_b, e->pn_a};
+  for (int i = 0; i < 3; ++i) {
+    const std::string cv = pre + std::to_string(1 + 4 * i), bn = pre + std::to_string(2 + 4 * i);
+    float* dst = bufs[i & 1];
+    conv5_bn_relu_kernel<<<(S + CONV_TT - 1) / CONV_TT, 256, (size_t)(CONV_TT + 4) * dd * 4, e->es>>>(
+        src, e->convT[which][i], W<float>(e, cv + ".bias"), W<float>(e, bn + ".weight"), W<float>(e, bn + ".bias"),
+        W<float>(e, bn + ".running_mean"), W<float>(e, bn + ".running_var"), dst, S, dd);
+    src = dst;
+  }
+  // src == pn_b after three convolutions
+  return linear_rows_f32(e, src, W<float>(e, pre + "14.weight"), W<float>(e, pre + "14.bias"), out, S, dd, dd, false);
+}
+// audio prenet (valle.py:115-123): `in` (rows, dd) -> `out` (rows, dd), hidden rows in pn_h1 / pn_h2
+static int audio_prenet_rows(vx_engine* e, int which, const float* in, float* out, int rows, int dd) {
+  const std::string pre = std::string(which ? "nar" : "ar") + "_audio_prenet.";
+  VXC(linear_rows_f32(e, in, W<float>(e, pre + "0.weight"), W<float>(e, pre + "0.bias"), e->pn_h1, rows, PRENET_H, dd, true));
+  VXC(linear_rows_f32(e, e->pn_h1, W<float>(e, pre + "3.weight"), W<float>(e, pre + "3.bias"), e->pn_h2, rows, PRENET_H, PRENET_H, true));
+  return linear_rows_f32(e, e->pn_h2, W<float>(e, pre + "6.weight"), W<float>(e, pre + "6.bias"), out, rows, dd, PRENET_H, false);
+}
+
 // rows of the fp32 residual stream -> the GEMM operand type, no normalisation (input of a post-norm stack)
 static int cast_rows(vx_engine* e, const float* x, void* out, size_t n) {
   if (e->bf16) convert_kernel<bf16><<<1024, 256, 0, e->es>>>(x, (bf16*)out, n);
@@ -627,10 +704,19 @@ static int prefill_impl(vx_engine* e, int slot, const int64_t* text, int32_t S, 
     HIPC(hipMemcpyAsync(e->ids_audio, &b, 8, hipMemcpyHostToDevice, e->es));
   }
   if (P) HIPC(hipMemcpyAsync(e->ids_audio + bos, prompt_cb0, (size_t)P * 8, hipMemcpyDefault, e->es));
-  embed_pos_kernel<<<S, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "ar_text_embedding.word_embeddings.weight"), 512, d,
-                                         W<float>(e, "ar_text_position.alpha"), e->pe_ar, 0, e->X, S);
-  embed_pos_kernel<<<A, 256, 0, e->es>>>(e->ids_audio, 1, 0, W<float>(e, "ar_audio_embedding.word_embeddings.weight"), 1025 + bos, d,
-                                         W<float>(e, "ar_audio_position.alpha"), e->pe_ar, 0, e->X + (size_t)S * d, A);
+  if (c.flags & VX_FLAG_PRENET) {  // embedding -> prenet -> position (valle.py:995-997, 1013-1015)
+    embed_accum_kernel<<<S, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "ar_text_embedding.word_embeddings.weight"), 512, d, e->pn_a, S, 1);
+    VXC(text_prenet_rows(e, 0, e->pn_a, e->pn_a, S, d));
+    add_pos_kernel<<<S, 256, 0, e->es>>>(e->pn_a, d, W<float>(e, "ar_text_position.alpha"), e->pe_ar, 0, e->X, S);
+    embed_accum_kernel<<<A, 256, 0, e->es>>>(e->ids_audio, 1, 0, W<float>(e, "ar_audio_embedding.word_embeddings.weight"), 1025 + bos, d, e->pn_a, A, 1);
+    VXC(audio_prenet_rows(e, 0, e->pn_a, e->pn_b, A, d));
+    add_pos_kernel<<<A, 256, 0, e->es>>>(e->pn_b, d, W<float>(e, "ar_audio_position.alpha"), e->pe_ar, 0, e->X + (size_t)S * d, A);
+  } else {
+    embed_pos_kernel<<<S, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "ar_text_embedding.word_embeddings.weight"), 512, d,
+                                           W<float>(e, "ar_text_position.alpha"), e->pe_ar, 0, e->X, S);
+    embed_pos_kernel<<<A, 256, 0, e->es>>>(e->ids_audio, 1, 0, W<float>(e, "ar_audio_embedding.word_embeddings.weight"), 1025 + bos, d,
+                                           W<float>(e, "ar_audio_position.alpha"), e->pe_ar, 0, e->X + (size_t)S * d, A);
+  }
   char* kv_base = slot < 0 ? (char*)e->kv : (char*)(e->bkv + (size_t)slot * e->bkv_slot);
   float* x_dst = slot < 0 ? e->ar_x : e->bx + (size_t)slot * d;
   float* lg_dst = slot < 0 ? e->ar_logits : e->blogits + (size_t)slot * LOGITS_CUR;
@@ -774,7 +860,23 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
   sa.emb = W<float>(e, "ar_audio_embedding.word_embeddings.weight");
   sa.alpha = W<float>(e, "ar_audio_position.alpha");
   sa.pe = e->pe_ar; sa.x = e->ar_x; sa.d = d;
+  const bool prenet = c.flags & VX_FLAG_PRENET;
+  if (prenet) { sa.alpha = e->d_zero; sa.x = e->ar_e; }  // raw embedding; the position is added after the prenet
   sample_embed4_kernel<5, 17><<<1, 256, 0, s>>>(sa);
+  if (prenet) {  // y_emb = ar_audio_prenet(E[tok]); x = y_emb + alpha * pe (valle.py:1013-1015): three fp32 GEMVs
+    GemvArgs p0{}, p1{}, p2{};
+    p0.st = p1.st = p2.st = e->d_st;
+    p0.W = W<void>(e, "ar_audio_prenet.0.weight"); p0.bias = W<float>(e, "ar_audio_prenet.0.bias");
+    p0.x = e->ar_e; p0.y = e->ar_h1; p0.N = PRENET_H; p0.K = d; p0.pro = PRO_COPY; p0.epi = EPI_RELU;
+    p1.W = W<void>(e, "ar_audio_prenet.3.weight"); p1.bias = W<float>(e, "ar_audio_prenet.3.bias");
+    p1.x = e->ar_h1; p1.y = e->ar_h2; p1.N = PRENET_H; p1.K = PRENET_H; p1.pro = PRO_COPY; p1.epi = EPI_RELU;
+    p2.W = W<void>(e, "ar_audio_prenet.6.weight"); p2.bias = W<float>(e, "ar_audio_prenet.6.bias");
+    p2.x = e->ar_h2; p2.y = e->ar_x; p2.N = d; p2.K = PRENET_H; p2.pro = PRO_COPY; p2.epi = EPI_POS;
+    p2.pe = e->pe_ar; p2.pos_alpha = W<float>(e, "ar_audio_position.alpha");
+    VXC(launch_gemv(false, p0, e->num_cu, s));
+    VXC(launch_gemv(false, p1, e->num_cu, s));
+    VXC(launch_gemv(false, p2, e->num_cu, s));
+  }
   const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd * e->esz;
   const float scale = 1.0f / sqrtf((float)hd);
   for (int li = 0; li < c.num_layers; ++li) {
@@ -1120,8 +1222,8 @@ extern "C" int vx_batch_result(vx_engine* e, int32_t slot, int64_t* tokens, int3
 }
 
 // ------------------------------------------------------------------------------ NAR
-extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
-                      const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream) {
+static int nar_impl(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
+                    const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream, bool pos_before_prenet) {
   if (!e || !text_nar || !ar_tokens || !codes_out || (P > 0 && !prompts)) return fail(VX_ERR_ARG, "null argument");
   if (!e->finalized) return fail(VX_ERR_STATE, "weights not finalized");
   const vx_config& c = e->cfg;
@@ -1145,10 +1247,27 @@ extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const i
       for (int j = 1; j < Q; ++j) embed_accum_kernel<<<P, 256, 0, e->es>>>(e->ids_prompts, Q, j, emb(j), 1024, dn, e->yemb, P, 0);
     const float* a_txt = W<float>(e, "nar_text_position.alpha");
     const float* a_aud = W<float>(e, "nar_audio_position.alpha");
+    const bool prenet = c.flags & VX_FLAG_PRENET;
+    if (prenet) {  // x = position(nar_text_prenet(embedding)) once (valle.py:1081-1083); kept in pn_text for every stage
+      embed_accum_kernel<<<S2, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "nar_text_embedding.word_embeddings.weight"), 512, dn, e->pn_a, S2, 1);
+      VXC(text_prenet_rows(e, 1, e->pn_a, e->pn_a, S2, dn));
+      add_pos_kernel<<<S2, 256, 0, e->es>>>(e->pn_a, dn, a_txt, e->pe_nar, 0, e->pn_text, S2);
+    }
     for (int i = 0; i < Q - 1; ++i) {
-      embed_pos_kernel<<<S2, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "nar_text_embedding.word_embeddings.weight"), 512, dn,
-                                              a_txt, e->pe_nar, 0, e->X, S2);
-      add_pos_kernel<<<A, 256, 0, e->es>>>(e->yemb, dn, a_aud, e->pe_nar, 0, e->X + (size_t)S2 * dn, A);
+      if (prenet) {
+        HIPC(hipMemcpyAsync(e->X, e->pn_text, (size_t)S2 * dn * 4, hipMemcpyDeviceToDevice, e->es));
+        if (pos_before_prenet) {  // VALLE.continual, prefix mode 0 (valle.py:1193-1194)
+          add_pos_kernel<<<A, 256, 0, e->es>>>(e->yemb, dn, a_aud, e->pe_nar, 0, e->pn_a, A);
+          VXC(audio_prenet_rows(e, 1, e->pn_a, e->X + (size_t)S2 * dn, A, dn));
+        } else {  // valle.py:1092-1093, 1121-1122
+          VXC(audio_prenet_rows(e, 1, e->yemb, e->pn_b, A, dn));
+          add_pos_kernel<<<A, 256, 0, e->es>>>(e->pn_b, dn, a_aud, e->pe_nar, 0, e->X + (size_t)S2 * dn, A);
+        }
+      } else {
+        embed_pos_kernel<<<S2, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "nar_text_embedding.word_embeddings.weight"), 512, dn,
+                                                a_txt, e->pe_nar, 0, e->X, S2);
+        add_pos_kernel<<<A, 256, 0, e->es>>>(e->yemb, dn, a_aud, e->pe_nar, 0, e->X + (size_t)S2 * dn, A);
+      }
       VXC(run_stack(e, e->nar_l, N, dn, c.nar_nhead, -1, i, false));
       // final AdaLN + predict layer on the T generated rows only (valle.py:1128)
       if (c.flags & VX_FLAG_POST_NORM) {  // no final norm (valle.py:242-246): the rows are already norm2'd
@@ -1178,6 +1297,16 @@ extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const i
   e->last_T = T; e->last_N = N;
   VXC(sync_out(e, stream));
   return VX_OK;
+}
+
+extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
+                      const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream) {
+  return nar_impl(e, text_nar, S2, prompts, P, ar_tokens, T, codes_out, stream, false);
+}
+
+extern "C" int vx_nar_continual(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
+                                const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream) {
+  return nar_impl(e, text_nar, S2, prompts, P, ar_tokens, T, codes_out, stream, e && e->cfg.prefix_mode == 0);
 }
 
 // Row buffers are sized for one utterance at vx_create; the batched NAR concatenates up to max_batch of them.
@@ -1228,6 +1357,7 @@ extern "C" int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_
   const int Q = c.num_quantizers, dn = c.nar_d_model;
   if (n < 1 || n > BMAX) return fail(VX_ERR_ARG, "n must be 1..%d", BMAX);
   if (!e->bf16 || !use_mfma(e) || Q < 2) return fail(VX_ERR_UNSUPPORTED, "vx_nar_batch needs bf16 MFMA rows and num_quantizers > 1");
+  if (c.flags & VX_FLAG_PRENET) return fail(VX_ERR_UNSUPPORTED, "vx_nar_batch: prenet models run on the batch-1 path only");
   HIPC(hipSetDevice(c.device));
   std::vector<int> start(n), len(n), aoff(n), toff(n), soff(n);
   size_t rows = 0, arows = 0, trows = 0, srows = 0;

@@ -47,6 +47,55 @@ __global__ __launch_bounds__(256) void embed_accum_kernel(const long long* __res
   }
 }
 
+// ---- text prenet (valle.py:97-113): Conv1d(d, d, kernel 5, padding same) + BatchNorm1d (running statistics) + ReLU ----
+// x, y: (S, d) row-major (the reference transposes to channels-first around the convolutions; same numbers).
+// wt: the Conv1d weight re-laid out as [k][ci][co] (vx_finalize_weights), so a wave reads consecutive co.
+// One workgroup = CONV_TT consecutive rows t, all co (thread = co, strided); the CONV_TT + 4 input rows it needs sit
+// in LDS and every weight is used CONV_TT times.
+constexpr int CONV_TT = 4;
+__global__ __launch_bounds__(256) void conv5_bn_relu_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                            const float* __restrict__ bias, const float* __restrict__ bn_g,
+                                                            const float* __restrict__ bn_b, const float* __restrict__ bn_mean,
+                                                            const float* __restrict__ bn_var, float* __restrict__ y, int S,
+                                                            int d) {
+  extern __shared__ float xs[];  // [(CONV_TT + 4)][d]
+  const int t0 = blockIdx.x * CONV_TT;
+  for (int i = threadIdx.x; i < (CONV_TT + 4) * d; i += 256) {
+    const int rr = i / d, c = i - rr * d, t = t0 + rr - 2;
+    xs[i] = (t >= 0 && t < S) ? x[(size_t)t * d + c] : 0.f;  // zero padding ("same")
+  }
+  __syncthreads();
+  for (int co = threadIdx.x; co < d; co += 256) {
+    float acc[CONV_TT];
+#pragma unroll
+    for (int j = 0; j < CONV_TT; ++j) acc[j] = 0.f;
+    for (int ci = 0; ci < d; ++ci) {
+      float w[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) w[k] = wt[((size_t)k * d + ci) * d + co];
+#pragma unroll
+      for (int j = 0; j < CONV_TT; ++j)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[j] = fmaf(w[k], xs[(j + k) * d + ci], acc[j]);
+    }
+    const float inv = 1.0f / sqrtf(bn_var[co] + 1e-5f);  // BatchNorm1d eps (torch default)
+#pragma unroll
+    for (int j = 0; j < CONV_TT; ++j) {
+      if (t0 + j >= S) break;
+      const float v = (acc[j] + bias[co] - bn_mean[co]) * inv * bn_g[co] + bn_b[co];
+      y[(size_t)(t0 + j) * d + co] = fmaxf(v, 0.f);
+    }
+  }
+}
+
+// [co][ci][k] (nn.Conv1d) -> [k][ci][co]
+__global__ __launch_bounds__(256) void conv_weight_relayout_kernel(const float* __restrict__ w, float* __restrict__ wt, int d) {
+  const size_t n = (size_t)d * d * 5, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k = (int)(i % 5), ci = (int)((i / 5) % d), co = (int)(i / (5 * (size_t)d));
+  wt[((size_t)k * d + ci) * d + co] = w[i];
+}
+
 // (Adaptive)LayerNorm, one wave per row: out = [w *] (LN(x) * gamma + beta) [+ b]
 // (modules/transformer.py:57-74, 93-108).  OT = float or bf16 (the GEMM A-operand type).
 template <typename OT>

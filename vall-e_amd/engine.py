@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvallex.so")
 
 VX_PREC_F32, VX_PREC_BF16 = 0, 1
-VX_FLAG_TRACE_LOGITS, VX_FLAG_NO_GRAPH, VX_FLAG_SIMPLE_ROWS, VX_FLAG_POST_NORM = 1, 2, 4, 8
+VX_FLAG_TRACE_LOGITS, VX_FLAG_NO_GRAPH, VX_FLAG_SIMPLE_ROWS, VX_FLAG_POST_NORM, VX_FLAG_PRENET = 1, 2, 4, 8, 16
 STOP_REASONS = {0: "none", 1: "eos_argmax", 2: "eos_sample", 3: "length", 4: "max_new"}
 
 
@@ -53,6 +53,7 @@ _SIGS = {
     "vx_ar_decode": (C.c_int, [C.c_void_p, C.POINTER(VxDecodeParams), C.c_void_p]),
     "vx_ar_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vx_nar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "vx_nar_continual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "vx_batch_prefill": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "vx_batch_prefill_all": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_int32), C.c_void_p]),
@@ -132,7 +133,8 @@ class Engine:
         c.precision = {"fp32": VX_PREC_F32, "f32": VX_PREC_F32, "bf16": VX_PREC_BF16}[precision]
         c.max_text, c.max_audio, c.device = max_text, max_audio, self.device
         c.flags = (VX_FLAG_TRACE_LOGITS if trace_logits else 0) | (VX_FLAG_NO_GRAPH if no_graph else 0) | \
-                  (VX_FLAG_SIMPLE_ROWS if simple_rows else 0) | (0 if getattr(cfg, "norm_first", True) else VX_FLAG_POST_NORM)
+                  (VX_FLAG_SIMPLE_ROWS if simple_rows else 0) | (0 if getattr(cfg, "norm_first", True) else VX_FLAG_POST_NORM) | \
+                  (VX_FLAG_PRENET if getattr(cfg, "add_prenet", False) else 0)
         c.max_batch = int(max_batch)
         self.max_text, self.max_audio, self.trace_logits, self.max_batch = max_text, max_audio, trace_logits, int(max_batch)
         self.mfma_rows = c.precision == VX_PREC_BF16 and not simple_rows
@@ -157,6 +159,8 @@ class Engine:
 
         keys = expected_keys(self.cfg)
         for k, shape in keys.items():
+            if k.endswith("num_batches_tracked"):  # BatchNorm's step counter: not read by the forward pass
+                continue
             t = sd[k].detach().to(torch.float32).contiguous()
             assert tuple(t.shape) == tuple(shape), (k, tuple(t.shape), shape)
             shp = (C.c_int64 * t.dim())(*t.shape)
@@ -201,15 +205,17 @@ class Engine:
         _check(self.lib.vx_ar_result(self.h, _ptr(toks), n.value, C.byref(n), C.byref(reason), C.byref(npass)))
         return toks, reason.value, npass.value
 
-    def nar(self, text_nar: torch.Tensor, prompts: torch.Tensor, ar_tokens: torch.Tensor, out_device=None, stream=None):
-        """prompts: (P, Q); returns codes (T, Q) int64 on ``out_device`` (default: prompts' device)."""
+    def nar(self, text_nar: torch.Tensor, prompts: torch.Tensor, ar_tokens: torch.Tensor, out_device=None, stream=None,
+            continual: bool = False):
+        """prompts: (P, Q); returns codes (T, Q) int64 on ``out_device`` (default: prompts' device).  ``continual``:
+        the NAR body of VALLE.continual (vx_nar_continual)."""
         text_nar = text_nar.to(torch.int64).contiguous()
         prompts = prompts.to(torch.int64).contiguous()
         ar_tokens = ar_tokens.to(torch.int64).contiguous()
         T, Q = ar_tokens.numel(), self.cfg.num_quantizers
         out = torch.empty((T, Q), dtype=torch.int64, device=out_device if out_device is not None else prompts.device)
-        _check(self.lib.vx_nar(self.h, _ptr(text_nar), text_nar.numel(), _ptr(prompts), prompts.shape[0],
-                               _ptr(ar_tokens), T, _ptr(out), stream))
+        fn = self.lib.vx_nar_continual if continual else self.lib.vx_nar
+        _check(fn(self.h, _ptr(text_nar), text_nar.numel(), _ptr(prompts), prompts.shape[0], _ptr(ar_tokens), T, _ptr(out), stream))
         return out
 
     # -- batched decode (BASELINE configs[2]) -------------------------------------------------------

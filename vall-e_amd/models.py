@@ -41,10 +41,8 @@ class VALLE:
                                num_quantizers=kwargs.pop("num_quantizers", 8))
         if kwargs:
             raise TypeError(f"unexpected arguments {sorted(kwargs)}")
-        if add_prenet:
-            raise NotImplementedError("add_prenet=True (valle.py:96-123) is outside the built scope (DESIGN.md)")
-        if not norm_first and self.engine_opts.get("max_batch", 0) > 1:
-            raise NotImplementedError("norm_first=False runs on the batch-1 path only (inference_batch needs pre-norm)")
+        if (not norm_first or add_prenet) and self.engine_opts.get("max_batch", 0) > 1:
+            raise NotImplementedError("norm_first=False / add_prenet=True run on the batch-1 path only (inference_batch needs the defaults)")
         if self.cfg.num_quantizers > 1 and (self.cfg.nar_nhead <= 0 or self.cfg.nar_dim != 64 * self.cfg.nar_nhead):
             raise NotImplementedError("nar_scale_factor must keep the NAR head_dim at 64 (DESIGN.md)")
         self.ar_audio_prepend_bos = self.cfg.prepend_bos
@@ -71,7 +69,8 @@ class VALLE:
                                f"size mismatch {bad}")
         for k in want:
             if k in state_dict:
-                self._sd[k] = state_dict[k].detach().to("cpu", torch.float32).contiguous()
+                keep = k.endswith("num_batches_tracked")  # int64 scalar of BatchNorm1d
+                self._sd[k] = state_dict[k].detach().to("cpu", state_dict[k].dtype if keep else torch.float32).contiguous()
         if self.cfg.share_embedding:  # valle.py:261-271: tied tensors are one storage
             for pk, ek in tied_keys(self.cfg).items():
                 if pk in state_dict and ek in state_dict and not torch.equal(self._sd[pk], self._sd[ek]):
@@ -238,7 +237,7 @@ class VALLE:
         prefix_len = min(int(y.shape[1] * 0.5), 3 * 75)
         prompts = y[0, :prefix_len, :8].contiguous()
         rest0 = y[0, prefix_len:, 0].contiguous()
-        codes = eng.nar(x[0], prompts, rest0, out_device=self.device)
+        codes = eng.nar(x[0], prompts, rest0, out_device=self.device, continual=True)
         return codes.unsqueeze(0)
 
 

@@ -58,16 +58,47 @@ def _encoder_keys(prefix: str, d: int, layers: int, adaptive: bool, final_norm: 
     return out
 
 
+PRENET_HIDDEN = 256  # valle.py:116-122
+
+
+def _prenet_keys(prefix: str, d: int) -> "OrderedDict[str, Tuple[int, ...]]":
+    """{ar,nar}_text_prenet = Sequential(Transpose, [Conv1d(d,d,5,same), BatchNorm1d, ReLU, Dropout] x 3, Transpose,
+    Linear(d,d)); {ar,nar}_audio_prenet = Linear(d,256), ReLU, Dropout, Linear(256,256), ReLU, Dropout, Linear(256,d)
+    (valle.py:96-123, 181-213).  Module indices are the Sequential positions."""
+    out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    t = f"{prefix}_text_prenet"
+    for conv, bn in ((1, 2), (5, 6), (9, 10)):
+        out[f"{t}.{conv}.weight"] = (d, d, 5)
+        out[f"{t}.{conv}.bias"] = (d,)
+        out[f"{t}.{bn}.weight"] = (d,)
+        out[f"{t}.{bn}.bias"] = (d,)
+        out[f"{t}.{bn}.running_mean"] = (d,)
+        out[f"{t}.{bn}.running_var"] = (d,)
+        out[f"{t}.{bn}.num_batches_tracked"] = ()
+    out[f"{t}.14.weight"] = (d, d)
+    out[f"{t}.14.bias"] = (d,)
+    a = f"{prefix}_audio_prenet"
+    out[f"{a}.0.weight"] = (PRENET_HIDDEN, d)
+    out[f"{a}.0.bias"] = (PRENET_HIDDEN,)
+    out[f"{a}.3.weight"] = (PRENET_HIDDEN, PRENET_HIDDEN)
+    out[f"{a}.3.bias"] = (PRENET_HIDDEN,)
+    out[f"{a}.6.weight"] = (d, PRENET_HIDDEN)
+    out[f"{a}.6.bias"] = (d,)
+    return out
+
+
 def expected_keys(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
-    """state_dict keys -> shapes for VALLE(add_prenet=False) (valle.py:85-259).  372 entries at L=12 / 8 quantizers
-    with norm_first=True; post-norm models have no final encoder norms."""
-    assert not cfg.add_prenet, "prenets are not built"
+    """state_dict keys -> shapes for VALLE (valle.py:85-259).  372 entries at L=12 / 8 quantizers with the defaults;
+    post-norm models have no final encoder norms, add_prenet adds the four prenets.  Key ORDER follows the
+    reference's module registration order."""
     d, dn = cfg.decoder_dim, cfg.nar_dim
     q = cfg.num_quantizers
     k: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     k["ar_text_embedding.word_embeddings.weight"] = (NUM_TEXT_TOKENS, d)
     k["nar_text_embedding.word_embeddings.weight"] = (NUM_TEXT_TOKENS, dn)
     k["ar_audio_embedding.word_embeddings.weight"] = (NUM_AUDIO_TOKENS + 1 + int(cfg.prepend_bos), d)
+    if cfg.add_prenet:
+        k.update(_prenet_keys("ar", d))
     k["ar_text_position.alpha"] = (1,)
     k["ar_audio_position.alpha"] = (1,)
     k.update(_encoder_keys("ar_decoder", d, cfg.num_decoder_layers, adaptive=False, final_norm=cfg.norm_first))
@@ -76,6 +107,8 @@ def expected_keys(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
         k["nar_audio_embeddings.0.word_embeddings.weight"] = (NUM_AUDIO_TOKENS + 1, dn)
         for j in range(1, q):
             k[f"nar_audio_embeddings.{j}.word_embeddings.weight"] = (NUM_AUDIO_TOKENS, dn)
+        if cfg.add_prenet:
+            k.update(_prenet_keys("nar", dn))
         k["nar_text_position.alpha"] = (1,)
         k["nar_audio_position.alpha"] = (1,)
         k.update(_encoder_keys("nar_decoder", dn, cfg.nar_layers, adaptive=True, final_norm=cfg.norm_first))
@@ -117,6 +150,17 @@ def synthetic_tensor(key: str, shape: Tuple[int, ...], seed: int = 0) -> torch.T
         return torch.ones(1)  # NAR alphas are frozen at 1.0 (valle.py:218-229)
     if "word_embeddings" in key:
         return torch.randn(shape, generator=g)
+    if "_prenet." in key:
+        if key.endswith("num_batches_tracked"):
+            return torch.tensor(0, dtype=torch.int64)
+        if key.endswith("running_mean"):
+            return 0.1 * torch.randn(shape, generator=g)
+        if key.endswith("running_var"):
+            return 0.5 + torch.rand(shape, generator=g)
+        if len(shape) == 3:  # Conv1d: U(+-1/sqrt(fan_in)), fan_in = in_channels * kernel
+            return (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(shape[1] * shape[2])
+        if len(shape) == 1 and ".weight" in key and key.split(".")[-2] in ("2", "6", "10") and "text_prenet" in key:
+            return 1.0 + 0.05 * torch.randn(shape, generator=g)  # BatchNorm gamma
     if key.endswith("in_proj_weight"):
         bound = math.sqrt(6.0 / (shape[0] + shape[1]))
         return (torch.rand(shape, generator=g) * 2 - 1) * bound
