@@ -189,7 +189,7 @@ def main():
                                     f"S={S_TEXT} P={P_PROMPT} -> T={T} frames x 8 codebooks, one utterance per GPU per step")
                        if Bt == 1 else
                        (f"BASELINE configs[2]: d=1024 nhead=16 L=12, batch={Bt} concurrent utterances per GPU (padded KV, "
-                        f"hipGraph step) + per-utterance NAR, S={S_TEXT} P={P_PROMPT} -> T={T} x 8"),
+                        f"hipGraph step, one batched prefill and one batched NAR pass), S={S_TEXT} P={P_PROMPT} -> T={T} x 8"),
                        "parallelism": f"replica x{world} (utterance sharding, RCCL scatter/gather)"},
             "ar_tokens_per_s": round(tm["launches"] / (tm["decode_ms"] * 1e-3), 1),
             "ar_step_us": round(step_s * 1e6, 2),

@@ -103,3 +103,29 @@ def test_key_table_is_372_entries_at_baseline_config():
             p *= v
         n += p
     assert n == 367386628
+
+
+def _layouts():
+    import json
+
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_dict_layout.json")))
+
+
+@pytest.mark.parametrize("case", sorted(_layouts()))
+def test_state_dict_layout_matches_reference(case):
+    """tests/golden/state_dict_layout.json is the reference's own `get_model(params).state_dict()` (names, order, shapes,
+    dtypes, tied storage) for each constructor option the build supports (oracle/gen_keys.py): the loader contract of
+    bin/infer.py:139-143 (`load_state_dict(checkpoint["model"], strict=True)`)."""
+    from valle_amd.config import ModelConfig
+    from valle_amd.weights import expected_keys, synthetic_state_dict, tied_keys
+
+    ref = _layouts()[case]
+    cfg = ModelConfig(**ref["cfg"])
+    want = expected_keys(cfg)
+    assert [k for k, _, _ in ref["keys"]] == list(want)  # same names, same order
+    for k, shape, dtype in ref["keys"]:
+        assert tuple(shape) == tuple(want[k]), k
+    sd = synthetic_state_dict(cfg, 0)
+    for k, shape, dtype in ref["keys"]:
+        assert str(sd[k].dtype).replace("torch.", "") == dtype, k
+    assert sorted((a, b) for a, b in ref["shared"]) == sorted(tied_keys(cfg).items())  # valle.py:261-271
