@@ -197,6 +197,9 @@ int vx_debug_launch_floor(int32_t n_kernels, int32_t grid, int32_t block, int32_
  * rows in {4,12,16} = output rows per workgroup per stage.  out[0] us/launch, out[1] us/stage, out[2] max |err|
  * against a host evaluation of the same chain, out[3] != 0 when a bounded spin ran out. */
 int vx_debug_stage_chain(int32_t nwg, int32_t stages, int32_t rows, int32_t mode, int32_t iters, double* out);
+/* Probe: L2 -> CU fill rate.  `grid` workgroups of `threads` lanes stream one shared region of `region_bytes` with `unroll`
+ * independent 16-byte loads in flight per lane.  out[0] GB/s chip-wide, out[1] bytes/clock per busy CU, out[2] clock (GHz). */
+int vx_debug_l2_fill(int32_t grid, int32_t threads, int32_t unroll, int64_t region_bytes, int32_t iters, double* out);
 
 #ifdef __cplusplus
 }

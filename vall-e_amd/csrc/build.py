@@ -11,7 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "libvallex.so")
 SRCS = ["engine.hip"]
-DEPS = SRCS + ["common.hpp", "ar_kernels.hpp", "rows_kernels.hpp", "mfma_kernels.hpp", "batch_kernels.hpp", "../../include/vallex.h", "build.py"]
+# every header next to this file is a dependency (a hand-kept list went stale once: an edited header did not trigger a rebuild)
+DEPS = SRCS + sorted(f for f in os.listdir(HERE) if f.endswith(".hpp")) + ["../../include/vallex.h", "build.py"]
 
 
 def stale() -> bool:

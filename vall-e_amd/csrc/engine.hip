@@ -1718,3 +1718,53 @@ extern "C" int vx_debug_stage_chain(int32_t nwg, int32_t stages, int32_t rows, i
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
   return VX_OK;
 }
+
+
+// L2 -> CU fill-rate probe (persist_probe.hpp): grid workgroups of `threads` lanes, `unroll` 16-byte loads in flight
+// per lane, all over one shared region of `region_bytes` (keep it below the 4 MB of an XCD's L2).
+// out[0] = GB/s over the whole chip, out[1] = bytes per clock per CU at the clock in out[2] (GHz, from wall_clock).
+extern "C" int vx_debug_l2_fill(int32_t grid, int32_t threads, int32_t unroll, int64_t region_bytes, int32_t iters, double* out) {
+  if (!out || grid <= 0 || grid > 4096 || threads <= 0 || threads > 256 || threads % 64 || iters <= 0 || region_bytes < 65536)
+    return fail(VX_ERR_ARG, "bad argument");
+  if (unroll != 1 && unroll != 2 && unroll != 4 && unroll != 8 && unroll != 16) return fail(VX_ERR_ARG, "unroll must be 1/2/4/8/16");
+  const size_t nvec = (size_t)region_bytes / 16;
+  uint4* buf = nullptr; unsigned* sink = nullptr;
+  HIPC(hipMalloc((void**)&buf, nvec * 16));
+  HIPC(hipMalloc((void**)&sink, 16));
+  HIPC(hipMemset(buf, 1, nvec * 16));
+  hipStream_t s;
+  HIPC(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  hipEvent_t e0, e1;
+  HIPC(hipEventCreate(&e0));
+  HIPC(hipEventCreate(&e1));
+  auto launch = [&]() {
+    switch (unroll) {
+      case 1: l2_fill_kernel<1><<<grid, threads, 0, s>>>(buf, nvec, iters, sink); break;
+      case 2: l2_fill_kernel<2><<<grid, threads, 0, s>>>(buf, nvec, iters, sink); break;
+      case 4: l2_fill_kernel<4><<<grid, threads, 0, s>>>(buf, nvec, iters, sink); break;
+      case 8: l2_fill_kernel<8><<<grid, threads, 0, s>>>(buf, nvec, iters, sink); break;
+      default: l2_fill_kernel<16><<<grid, threads, 0, s>>>(buf, nvec, iters, sink); break;
+    }
+  };
+  launch();
+  HIPC(hipStreamSynchronize(s));
+  HIPC(hipEventRecord(e0, s));
+  launch();
+  HIPC(hipEventRecord(e1, s));
+  HIPC(hipStreamSynchronize(s));
+  HIPC(hipGetLastError());
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = (double)grid * threads * 16.0 * unroll * iters;
+  hipDeviceProp_t prop;
+  HIPC(hipGetDeviceProperties(&prop, 0));
+  const double ghz = prop.clockRate * 1e-6;
+  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  const int busy = grid < cus ? grid : cus;
+  out[0] = bytes / (ms * 1e-3) / 1e9;
+  out[1] = bytes / (ms * 1e-3) / (ghz * 1e9) / busy;
+  out[2] = ghz;
+  (void)hipFree(buf); (void)hipFree(sink);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+  return VX_OK;
+}

@@ -104,3 +104,30 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
 }
 
 }  // namespace vx
+
+// ---- probe: L2 -> CU fill rate.  Every workgroup streams a small, L2-resident window (all workgroups share one
+// `region_bytes` region, so after the first touch everything is served by the XCD's L2) with U independent 16-byte
+// loads in flight per lane.  Answers: how many bytes per clock can one CU pull from L2, and does it scale with
+// the number of resident waves or with the loads in flight per wave?  (The GEMM tiles are sized against this.)
+namespace vx {
+template <int U>
+__global__ __launch_bounds__(256) void l2_fill_kernel(const uint4* __restrict__ buf, size_t region_vec, int iters,
+                                                      unsigned* __restrict__ sink) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+  size_t p = tid % region_vec;
+  const size_t stride = ((size_t)gridDim.x * blockDim.x) % region_vec;  // < region_vec: one conditional subtraction keeps p in range
+  for (int it = 0; it < iters; ++it) {
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = buf[p];
+      p += stride;
+      if (p >= region_vec) p -= region_vec;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { acc.x ^= v[u].x; acc.y ^= v[u].y; acc.z ^= v[u].z; acc.w ^= v[u].w; }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc.x;  // keeps the loads alive
+}
+}  // namespace vx

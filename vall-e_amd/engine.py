@@ -70,6 +70,7 @@ _SIGS = {
     "vx_op_convert_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "vx_debug_launch_floor": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "vx_debug_stage_chain": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_double)]),
+    "vx_debug_l2_fill": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
 }
 
 
@@ -355,3 +356,10 @@ def stage_chain(nwg=256, stages=60, rows=12, mode=2, iters=20):
     out = (C.c_double * 4)()
     _check(lib.vx_debug_stage_chain(nwg, stages, rows, mode, iters, out))
     return dict(us_per_launch=out[0], us_per_stage=out[1], max_err=out[2], spin_timeout=int(out[3]))
+
+
+def l2_fill(grid=256, threads=256, unroll=8, region_bytes=2 << 20, iters=200):
+    lib = load_library()
+    out = (C.c_double * 3)()
+    _check(lib.vx_debug_l2_fill(grid, threads, unroll, region_bytes, iters, out))
+    return dict(gbs=out[0], bytes_per_clk_per_cu=out[1], ghz=out[2])
