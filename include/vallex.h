@@ -193,7 +193,7 @@ int vx_op_convert_bf16(const float* src, void* dst_bf16, int64_t n, void* stream
  * n trivial kernels, out[0] replayed as a hipGraph, out[1] launched eagerly. */
 int vx_debug_launch_floor(int32_t n_kernels, int32_t grid, int32_t block, int32_t iters, double* out);
 /* Probe for a single-launch decode step: `stages` dependent 1024-wide GEMV stages in ONE kernel, separated by a
- * device-wide barrier (mode 0 = barrier only, 1 = release/acquire fences, 2 = agent-scope loads/stores + counter, 3 = as 2 with the barrier among groups of 8 workgroups only: timing, results unchecked).
+ * device-wide barrier (mode 0 = barrier only, 1 = release/acquire fences, 2 = agent-scope loads/stores + counter, 3 = as 2 with the barrier among groups of 8 consecutive workgroups only, 4 = among the workgroups with equal blockIdx % 8: timing, results unchecked).
  * rows in {4,12,16} = output rows per workgroup per stage.  out[0] us/launch, out[1] us/stage, out[2] max |err|
  * against a host evaluation of the same chain, out[3] != 0 when a bounded spin ran out. */
 int vx_debug_stage_chain(int32_t nwg, int32_t stages, int32_t rows, int32_t mode, int32_t iters, double* out);

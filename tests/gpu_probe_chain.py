@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import valle_amd  # noqa
 from valle_amd.engine import stage_chain, launch_floor
 
-for nwg, rows in ((256, 12), (256, 4), (128, 16)):
-    for mode in (0, 2, 3):
+for nwg, rows in ((256, 12), (256, 4)):
+    for mode in (0, 2, 3, 4):
         r = stage_chain(nwg=nwg, stages=60, rows=rows, mode=mode, iters=20)
         print(json.dumps(dict(nwg=nwg, rows=rows, mode=mode, **r)), flush=True)
         if r["spin_timeout"]:

@@ -1635,12 +1635,13 @@ static hipError_t launch_chain(int mode, int nwg, const ChainArgs& a, hipStream_
   if (mode == CHAIN_BARRIER_ONLY) chain_kernel<ROWS, CHAIN_BARRIER_ONLY><<<nwg, 256, 0, s>>>(a);
   else if (mode == CHAIN_FENCE) chain_kernel<ROWS, CHAIN_FENCE><<<nwg, 256, 0, s>>>(a);
   else if (mode == CHAIN_GROUP8) chain_kernel<ROWS, CHAIN_GROUP8><<<nwg, 256, 0, s>>>(a);
+  else if (mode == CHAIN_XCD) chain_kernel<ROWS, CHAIN_XCD><<<nwg, 256, 0, s>>>(a);
   else chain_kernel<ROWS, CHAIN_BYPASS><<<nwg, 256, 0, s>>>(a);
   return hipGetLastError();
 }
 
 extern "C" int vx_debug_stage_chain(int32_t nwg, int32_t stages, int32_t rows, int32_t mode, int32_t iters, double* out) {
-  if (!out || nwg <= 0 || nwg > 1024 || stages <= 0 || stages > 256 || iters <= 0 || mode < 0 || mode > 3)
+  if (!out || nwg <= 0 || nwg > 1024 || stages <= 0 || stages > 256 || iters <= 0 || mode < 0 || mode > 4 || (mode == 4 && nwg % 8))
     return fail(VX_ERR_ARG, "bad argument");
   if (rows != 4 && rows != 12 && rows != 16) return fail(VX_ERR_ARG, "rows must be 4, 12 or 16");
   if (nwg * rows < 1024) return fail(VX_ERR_ARG, "nwg*rows must cover the 1024-wide vector");

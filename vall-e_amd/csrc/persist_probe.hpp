@@ -22,7 +22,7 @@ struct ChainArgs {
   int stages, rows, mode;
 };
 
-enum { CHAIN_BARRIER_ONLY = 0, CHAIN_FENCE = 1, CHAIN_BYPASS = 2, CHAIN_GROUP8 = 3 };  // GROUP8: BYPASS data path, barrier among 8 neighbours only (timing probe: results unchecked)
+enum { CHAIN_BARRIER_ONLY = 0, CHAIN_FENCE = 1, CHAIN_BYPASS = 2, CHAIN_GROUP8 = 3, CHAIN_XCD = 4 };  // XCD: as GROUP8, but a group = the workgroups with equal blockIdx % 8 (one XCD under round-robin placement)  // GROUP8: BYPASS data path, barrier among 8 neighbours only (timing probe: results unchecked)
 
 template <int ROWS, int MODE>
 __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
@@ -32,9 +32,9 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
   __shared__ float red[4][NI];
   const size_t slice = (size_t)ROWS * 1024;
   const int nout = nwg * ROWS;
-  constexpr bool GROUP = MODE == CHAIN_GROUP8;
-  unsigned* ctr = GROUP ? a.ctr + 64 * (1 + wg / 8) : a.ctr;  // one counter per 256-byte line
-  const unsigned arrivals = GROUP ? 8u : (unsigned)nwg;
+  constexpr bool GROUP = MODE == CHAIN_GROUP8 || MODE == CHAIN_XCD;
+  unsigned* ctr = MODE == CHAIN_XCD ? a.ctr + 64 * (1 + (wg & 7)) : GROUP ? a.ctr + 64 * (1 + wg / 8) : a.ctr;  // one counter per 256-byte line
+  const unsigned arrivals = MODE == CHAIN_XCD ? (unsigned)(nwg / 8) : GROUP ? 8u : (unsigned)nwg;
   for (int s = 0; s < a.stages; ++s) {
     uint4 w[NI];
     if (MODE != CHAIN_BARRIER_ONLY) {
