@@ -46,6 +46,9 @@ CASES = {
     "tiny_q2_unshared": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=1, num_quantizers=2, share_embedding=False), 5, 12, 1, 1.0, None, None, (0, 3)),
     # nar_scale_factor = 0.5 (valle_test.py:131: "params.scale_factor = 0.5"): NAR stack of half width / heads / depth
     "tiny_scale05": (dict(decoder_dim=256, nhead=4, num_decoder_layers=4, prefix_mode=1, scale_factor=0.5), 6, 12, 4, 1.0, 11, None, (0, 9)),
+    # empty prompt: only possible with prepend_bos (the BOS row is then the whole audio prefix, valle.py:1006-1007)
+    "tiny_bos_empty_prompt": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=1, prepend_bos=True), 5, 0, 3, 1.0, 41, None, (0, 5)),
+    "tiny_bos_empty_prompt_mode0": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=0, prepend_bos=True), 4, 0, 1, 1.0, None, None, (0, 5)),
     # norm_first=False, the ordering the reference's own smoke test builds (valle_test.py:105: "params.norm_first = False")
     "tiny_postnorm": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=1, norm_first=False), 7, 14, 4, 1.0, 21, None, (0, 5)),
     "tiny_postnorm_mode0": (dict(decoder_dim=128, nhead=2, num_decoder_layers=3, prefix_mode=0, norm_first=False), 6, 10, 1, 1.0, None, None, (0, 5)),

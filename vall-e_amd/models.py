@@ -127,7 +127,8 @@ class VALLE:
             raise RuntimeError(f"x must be one unpadded sequence: x {tuple(x.shape)} vs x_lens.max() {S}")
         eng = self.engine()
         Q, bos = self.num_quantizers, int(self.ar_audio_prepend_bos)
-        if int(x.min()) < 0 or int(x.max()) >= NUM_TEXT_TOKENS or int(y.min()) < 0 or int(y[..., :Q].max()) >= NUM_AUDIO_TOKENS:
+        if int(x.min()) < 0 or int(x.max()) >= NUM_TEXT_TOKENS or (y.shape[1] > 0 and (  # an empty prompt is legal with prepend_bos
+                int(y.min()) < 0 or int(y[..., :Q].max()) >= NUM_AUDIO_TOKENS)):
             raise IndexError("index out of range in self")  # what nn.Embedding raises in the reference
         text = x[0]
         prompts = y[0, :, :Q].contiguous()
@@ -186,7 +187,8 @@ class VALLE:
                 assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3 and y.shape[0] == 1 and torch.all(x_lens > 0)
                 if x.shape[1] != int(x_lens.max()) or x.shape[0] != 1:
                     raise RuntimeError("x must be one unpadded sequence per utterance")
-                if int(x.min()) < 0 or int(x.max()) >= NUM_TEXT_TOKENS or int(y.min()) < 0 or int(y[..., :Q].max()) >= NUM_AUDIO_TOKENS:
+                if int(x.min()) < 0 or int(x.max()) >= NUM_TEXT_TOKENS or (y.shape[1] > 0 and (  # an empty prompt is legal with prepend_bos
+                int(y.min()) < 0 or int(y[..., :Q].max()) >= NUM_AUDIO_TOKENS)):
                     raise IndexError("index out of range in self")
                 if not (batched_prefill and eng.mfma_rows):
                     eng.batch_prefill(b, x[0], y[0, :, 0].contiguous())
