@@ -164,13 +164,28 @@ def test_batched_nar_matches_per_utterance_nar_and_reference():
     assert torch.equal(eng.nar(texts[0], proms[0], tks[0]).cpu(), single[0])
 
 
-def test_batched_prefill_matches_per_slot_prefill():
+@pytest.mark.parametrize("bos", [False, True])
+def test_batched_prefill_matches_per_slot_prefill(bos):
     """vx_batch_prefill_all (one pass over the concatenated rows, per-segment prefix mask, K/V scattered straight into
     every slot's cache) against n calls of vx_batch_prefill: same first logits within the bf16 tolerance, and the
     teacher-forced decode that follows reads the same caches (per-pass argmax agreement)."""
-    cfg, sd, m = _setup(max_batch=4)
+    if bos:  # prepend_bos adds a BOS row in front of the prompt; it is what makes an EMPTY prompt legal (slot 2)
+        import __graft_entry__ as ge
+
+        ge.build()
+        from valle_amd.config import ModelConfig
+        from valle_amd.models import VALLE
+        from valle_amd.weights import synthetic_state_dict
+
+        cfg = ModelConfig(decoder_dim=256, nhead=4, num_decoder_layers=4, prefix_mode=1, prepend_bos=True)
+        m = VALLE(256, 4, 4, prefix_mode=1, prepend_bos=True, precision="bf16", max_text=64, max_audio=700, print_eos=False, max_batch=4)
+        m.load_state_dict(synthetic_state_dict(cfg, 0))
+        m = m.to("cuda:0").eval()
+        utts = _utts([(6, 30), (9, 70), (4, 0), (11, 129)])
+    else:
+        cfg, sd, m = _setup(max_batch=4)
+        utts = _utts([(6, 30), (9, 70), (4, 55), (11, 129)])
     eng = m.engine()
-    utts = _utts([(6, 30), (9, 70), (4, 55), (11, 129)])
     texts = [u[0][0] for u in utts]
     proms = [u[2][0, :, 0].contiguous() for u in utts]
     forced = [torch.randint(0, 1024, (24,), generator=torch.Generator().manual_seed(5 + i)).cuda() for i in range(4)]
@@ -194,5 +209,5 @@ def test_batched_prefill_matches_per_slot_prefill():
     a = m.inference_batch(utts[:2], top_k=1, batched_prefill=True)
     b2 = m.inference_batch(utts[:2], top_k=1, batched_prefill=False)
     for x, y, u in zip(a, b2, utts):
-        assert x.shape == y.shape == (1, 16 * u[0].shape[1] + 1, 8)
+        assert x.shape == y.shape == (1, 16 * u[0].shape[1] + 1 - int(bos), 8)
         assert int(x.min()) >= 0 and int(x.max()) < 1024

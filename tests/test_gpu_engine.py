@@ -293,3 +293,49 @@ def test_max_new_tokens_extension():
     part = m.inference(x.cuda(), xl.cuda(), y.cuda(), None, top_k=1, max_new_tokens=11).cpu()
     assert part.shape == (1, 11, 8)
     assert torch.equal(part[..., 0], full[:, :11, 0])  # same AR prefix (NAR differs: it sees fewer frames)
+
+
+@pytest.mark.parametrize("seed", list(range(30)))
+def test_random_option_walk_matches_oracle(seed):
+    """Randomised constructor options / sizes / sampling parameters on a tiny model: the fp32 engine must produce the
+    oracle's codes exactly (the oracle is pinned to the reference on the committed fixtures; this widens the option
+    space the fixtures sample; oracle/check_random_walk.py ran the same 30 configurations through the unmodified reference
+    and asserted oracle == reference)."""
+    import random
+
+    from oracle import valle_oracle as vo
+    from valle_amd.config import ModelConfig
+    from valle_amd.models import VALLE
+    from valle_amd.weights import synthetic_inputs, synthetic_state_dict
+    import __graft_entry__ as ge
+
+    ge.build()
+    rnd = random.Random(1000 + seed)
+    mode = rnd.choice([0, 1, 2, 4])
+    bos = rnd.random() < 0.4
+    Q = rnd.choice([1, 2, 3, 5, 8])
+    kw = dict(decoder_dim=128, nhead=2, num_decoder_layers=rnd.choice([1, 2, 3]), prefix_mode=mode, prepend_bos=bos,
+              num_quantizers=Q, share_embedding=rnd.random() < 0.7, norm_first=rnd.random() < 0.6, add_prenet=rnd.random() < 0.3)
+    cfg = ModelConfig(**kw)
+    S = rnd.randint(3, 12)
+    P = rnd.choice([0, 1, 5, 17]) if bos else rnd.choice([1, 2, 9, 23])
+    top_k = rnd.choice([-100, 1, 2, 7, 1025])
+    temp = rnd.choice([1.0, 0.6, 1.7])
+    enroll = torch.tensor([rnd.randint(2, S - 1)], dtype=torch.int32) if mode in (2, 4) else None
+    sd = synthetic_state_dict(cfg, seed=seed)
+    x, xl, y = synthetic_inputs(S, P, 8, seed=50 + seed)
+    om = vo.OracleModel(sd, 128, 2, cfg.num_decoder_layers, mode, bos, Q, 1.0, cfg.norm_first, cfg.add_prenet)
+    noise = None
+    if top_k != 1:  # the draws torch.multinomial makes in the reference after torch.manual_seed(7 + seed): one (1,1025) per pass
+        torch.manual_seed(7 + seed)
+        noise = torch.stack([torch.empty(1, 1025).exponential_(1)[0] for _ in range(16 * S + 3)])
+    want = vo.inference_cached(om, x, xl, y, enroll, top_k, temp, noise)
+    m = VALLE(128, 2, cfg.num_decoder_layers, norm_first=cfg.norm_first, add_prenet=cfg.add_prenet, prefix_mode=mode,
+              share_embedding=cfg.share_embedding, prepend_bos=bos, num_quantizers=Q, precision="fp32", max_text=32, max_audio=400,
+              print_eos=False)
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    got = m.inference(x.cuda(), xl.cuda(), y.cuda(), enroll, top_k=top_k, temperature=temp,
+                      exp_noise=None if noise is None else noise.cuda()).cpu()
+    assert got.shape == want.shape, (kw, S, P, top_k, temp)
+    assert torch.equal(got, want), (kw, S, P, top_k, temp)
