@@ -117,27 +117,60 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
   if (kt + 1 < nk) step(I1{}, I2{}, kt + 1);
 
   // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+  if constexpr (!OUT_F32) {
+    // bf16 outputs (QKV, FFN1) leave through LDS: the accumulator layout has n on the lane and scattered m in its
+    // registers, so direct stores are 64 two-byte stores per lane (and fully scattered ones for the transposed V
+    // copy).  Staged as a bf16 [128][136] tile, every global store is 16 bytes and contiguous along n (C) or along
+    // m (V^T).  N % 128 == 0 and K loop done: the operand buffers are free.
+    constexpr int LDT = 136;  // row stride in elements (272 B): column reads for V^T hit distinct banks
+    bf16* tile = reinterpret_cast<bf16*>(lds);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + r;
-    const float bv = (EPI != GE_PLAIN && n < N) ? bias[n] : 0.f;
+    for (int j = 0; j < 2; ++j) {
+      const int nl = wn * 64 + j * 32 + r;
+      const float bv = (EPI != GE_PLAIN) ? bias[n0 + nl] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-        if (m < M && n < N) {
+        for (int v = 0; v < 16; ++v) {
+          const int ml = wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
           float x = acc[i][j][v] + bv;
           if (EPI == GE_RELU) x = fmaxf(x, 0.f);
-          if (OUT_F32) {
+          tile[ml * LDT + nl] = (bf16)x;
+        }
+    }
+    __syncthreads();
+    bf16* C = reinterpret_cast<bf16*>(Cv);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {  // 128 rows x 16 chunks of 8 elements
+      const int id = tid + 256 * q, row = id >> 4, c = id & 15;
+      if (m0 + row < M)
+        *reinterpret_cast<uint4*>(C + (size_t)(m0 + row) * N + n0 + c * 8) = *reinterpret_cast<const uint4*>(tile + row * LDT + c * 8);
+    }
+    if (vt != nullptr && n0 >= vt_n0) {  // a tile is 128 wide and vt_n0 a multiple of 128: all of it or none
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {  // 128 channels x 16 chunks of 8 rows; rows past M are finite padding keys
+        const int id = tid + 256 * q, nl = id >> 4, mc = id & 15;
+        union { bf16 e[8]; uint4 u; } pk;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pk.e[k] = tile[(mc * 8 + k) * LDT + nl];
+        *reinterpret_cast<uint4*>(vt + (size_t)(n0 + nl - vt_n0) * vt_ld + m0 + mc * 8) = pk.u;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + r;
+      const float bv = (EPI != GE_PLAIN && n < N) ? bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int m = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+          if (m < M && n < N) {
+            float x = acc[i][j][v] + bv;
+            if (EPI == GE_RELU) x = fmaxf(x, 0.f);
             float* c = reinterpret_cast<float*>(Cv) + (size_t)m * N + n;
             *c = (EPI == GE_RESID) ? (*c + x) : x;
-          } else {
-            reinterpret_cast<bf16*>(Cv)[(size_t)m * N + n] = (bf16)x;
-            // V columns of the packed QKV projection are also written transposed, (channel, row): the
-            // accumulator has its column on the lane, so this is contiguous in m for free and gives the
-            // flash-attention kernel its key-contiguous V operand without an in-kernel transpose.
-            if (vt != nullptr && n >= vt_n0) vt[(size_t)(n - vt_n0) * vt_ld + m] = (bf16)x;
           }
         }
       }
@@ -593,15 +626,19 @@ __device__ __forceinline__ float xor32_f(float v) {
   return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void mfma_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
-                                                            bf16* __restrict__ out, int M, int vt_ld, int d,
-                                                            int text_len, const int* __restrict__ seg_start,
-                                                            const int* __restrict__ seg_len,
-                                                            const int* __restrict__ seg_text) {
-  constexpr int HD = 64, NT = NW * 64;
-  // batched NAR: segment z of a concatenated row buffer (starts are multiples of 64 rows, so the 16-byte K / V^T
-  // tile loads stay aligned); single sequence: seg_start == nullptr
+// KG key groups: with KG = 2 the workgroup has 2 NW waves; wave (qw, kg) multiplies the 32 queries of slice qw
+// against key tiles kg, kg + 2, ... and the two partial softmaxes of a slice are merged through LDS at the end
+// (flash-decoding inside the workgroup).  Used when the (query block, head) grid alone gives each CU about one
+// workgroup (batch-1 NAR: 272 workgroups of 2 waves left two of the four SIMDs of every CU idle).
+template <int NW, int KG>
+__global__ __launch_bounds__(NW * KG * 64) void mfma_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
+                                                                 bf16* __restrict__ out, int M, int vt_ld, int d,
+                                                                 int text_len, const int* __restrict__ seg_start,
+                                                                 const int* __restrict__ seg_len,
+                                                                 const int* __restrict__ seg_text) {
+  constexpr int HD = 64, NT = NW * KG * 64;
+  // batched NAR / prefill: segment z of a concatenated row buffer (starts are multiples of 64 rows, so the 16-byte
+  // K / V^T tile loads stay aligned); single sequence: seg_start == nullptr
   if (seg_start != nullptr) {
     const int r0 = seg_start[blockIdx.z];
     M = seg_len[blockIdx.z];
@@ -611,12 +648,13 @@ __global__ __launch_bounds__(NW * 64) void mfma_attn_kernel(const bf16* __restri
     out += (size_t)r0 * d;
     vt += r0;
   }
-  constexpr int CPT = 512 / NT;  // 16-byte chunks per thread per operand tile (64 rows x 8 chunks)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][64 * 128];  // [buf][K | V^T][row * 128 B]
+  constexpr int CPT = 512 * KG / NT;  // 16-byte chunks per thread per operand per iteration (KG tiles of 64 rows x 8 chunks)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][KG][2][64 * 128];  // [buf][key group][K | V^T][row * 128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qw = wave % NW, kg = wave / NW;
   const int r = lane & 31, hh = lane >> 5;
   const int head = blockIdx.y;
-  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const int q0 = blockIdx.x * (32 * NW) + qw * 32;
   const int ld3 = 3 * d;
   const int qrow = q0 + r;
   const bool qvalid = qrow < M;
@@ -640,23 +678,25 @@ __global__ __launch_bounds__(NW * 64) void mfma_attn_kernel(const bf16* __restri
     blk_limit = last < text_len ? text_len : last + 1;
   }
   const int ntiles = (blk_limit + 63) / 64;
+  const int niter = (ntiles + KG - 1) / KG;  // iteration `it` stages tiles KG*it .. KG*it + KG-1 (past the end: masked)
 
   uint4 rk[CPT], rv[CPT];
-  auto gload = [&](int kt) {
+  auto gload = [&](int it) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const int q = tid + i * NT, row = q >> 3, c = q & 7;
-      rk[i] = ld16(qkv + (size_t)min(kt + row, M - 1) * ld3 + d + head * HD + c * 8);  // key row, 8 dims
-      rv[i] = ld16(vt + (size_t)(head * HD + row) * vt_ld + kt + c * 8);              // channel row, 8 keys
+      const int q = tid + i * NT, g = q >> 9, row = (q >> 3) & 63, c = q & 7;
+      const int kt = (it * KG + g) * 64;
+      rk[i] = ld16(qkv + (size_t)min(kt + row, M - 1) * ld3 + d + head * HD + c * 8);          // key row, 8 dims
+      rv[i] = ld16(vt + (size_t)(head * HD + row) * vt_ld + min(kt, (vt_ld - 64) & ~63) + c * 8);  // channel row, 8 keys
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const int q = tid + i * NT, row = q >> 3, c = q & 7;
+      const int q = tid + i * NT, g = q >> 9, row = (q >> 3) & 63, c = q & 7;
       const int off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
-      *reinterpret_cast<uint4*>(&lds[buf][0][off]) = rk[i];
-      *reinterpret_cast<uint4*>(&lds[buf][1][off]) = rv[i];
+      *reinterpret_cast<uint4*>(&lds[buf][g][0][off]) = rk[i];
+      *reinterpret_cast<uint4*>(&lds[buf][g][1][off]) = rv[i];
     }
   };
 
@@ -670,11 +710,11 @@ __global__ __launch_bounds__(NW * 64) void mfma_attn_kernel(const bf16* __restri
   gload(0);
   lstore(0);
   __syncthreads();
-  for (int it = 0; it < ntiles; ++it) {
-    const int cur = it & 1, kt = it * 64;
-    if (it + 1 < ntiles) gload(kt + 64);
-    const unsigned char* kb = &lds[cur][0][0];
-    const unsigned char* vb = &lds[cur][1][0];
+  for (int it = 0; it < niter; ++it) {
+    const int cur = it & 1, kt = (it * KG + kg) * 64;
+    if (it + 1 < niter) gload(it + 1);
+    const unsigned char* kb = &lds[cur][kg][0][0];
+    const unsigned char* vb = &lds[cur][kg][1][0];
     // S^T for the two 32-key sub-tiles
     f32x16_t accS[2];
 #pragma unroll
@@ -694,8 +734,8 @@ __global__ __launch_bounds__(NW * 64) void mfma_attn_kernel(const bf16* __restri
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int kg = kt + sub * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
-        const float sv = (kg < limit) ? accS[sub][v] : -INFINITY;
+        const int kgi = kt + sub * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
+        const float sv = (kgi < limit) ? accS[sub][v] : -INFINITY;
         accS[sub][v] = sv;
         mloc = fmaxf(mloc, sv);
       }
@@ -735,10 +775,34 @@ __global__ __launch_bounds__(NW * 64) void mfma_attn_kernel(const bf16* __restri
           accO[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v8, pf[sub][s2], accO[t], 0, 0, 0);
         }
       }
-    if (it + 1 < ntiles) lstore(cur ^ 1);
+    if (it + 1 < niter) lstore(cur ^ 1);
     __syncthreads();
   }
-  const float l_tot = l_run + xor32_f(l_run);
+  float l_tot = l_run + xor32_f(l_run);
+  if constexpr (KG == 2) {
+    // merge the two key groups of every query slice: group 1 parks (m, l, O^T) in LDS (the operand buffers are free
+    // after the loop's last barrier), group 0 rescales both to the common maximum and finishes
+    float* park = reinterpret_cast<float*>(&lds[0][0][0][0]) + (size_t)qw * 64 * 36;  // 34 used floats per lane, stride 36
+    if (kg == 1) {
+      float* p = park + lane * 36;
+      p[0] = m_run; p[1] = l_tot;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; v += 4) *reinterpret_cast<float4*>(p + 4 + t * 16 + v) = make_float4(accO[t][v], accO[t][v + 1], accO[t][v + 2], accO[t][v + 3]);
+    }
+    __syncthreads();
+    if (kg == 1) return;
+    const float* p = park + lane * 36;
+    const float m1 = p[0], l1 = p[1];
+    const float mm = fmaxf(m_run, m1);
+    const float f0 = (m_run == -INFINITY) ? 0.f : __expf(m_run - mm), f1 = (m1 == -INFINITY) ? 0.f : __expf(m1 - mm);
+    l_tot = l_tot * f0 + l1 * f1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) accO[t][v] = accO[t][v] * f0 + p[4 + t * 16 + v] * f1;
+  }
   if (qvalid) {
     const float inv = 1.0f / l_tot;
     bf16* op = out + (size_t)qrow * d + head * HD;
@@ -769,7 +833,11 @@ static inline int mfma_attn_dispatch(const bf16* qkv, const bf16* vt, int vt_ld,
   constexpr int NW = 2;
   const int rows = seg_start ? max_seg_len : M;
   dim3 grid((rows + 32 * NW - 1) / (32 * NW), H, seg_start ? nseg : 1);
-  mfma_attn_kernel<NW><<<grid, NW * 64, 0, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
+  // fewer than ~2 workgroups per CU: split the keys over two wave groups inside the workgroup (4 waves = all 4 SIMDs)
+  if ((long long)grid.x * grid.y * grid.z < 512)
+    mfma_attn_kernel<NW, 2><<<grid, NW * 2 * 64, 0, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
+  else
+    mfma_attn_kernel<NW, 1><<<grid, NW * 64, 0, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
   return 0;
 }
 
