@@ -589,22 +589,26 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
   __shared__ uint32_t s_T;
   const int slot = blockIdx.x;
   ArState* st = a.st + slot;
-  if (st->done) return;  // uniform
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = a.V;
-  const int pass = st->pass;
+  // the newest logits row sits at a fixed address, so its loads go out together with the state loads instead of
+  // one round trip behind the `done` test
   const float* lg = a.logits + (size_t)slot * a.logits_stride;
+  float v[NVT], qn[NVT];
+#pragma unroll
+  for (int j = 0; j < NVT; ++j) v[j] = lg[min(j * 256 + tid, V - 1)];
+  if (st->done) return;  // uniform
+  const int pass = st->pass;
   int* const tokens = a.tokens + (size_t)slot * a.tok_stride;
   int* const sampled = a.sampled + (size_t)slot * a.tok_stride;
   int* const argmaxes = a.argmaxes + (size_t)slot * a.tok_stride;
   float* const xout = a.x + (size_t)slot * a.d;
   const float* nz = st->exp_noise;
   if (nz != nullptr) nz += (size_t)min((long long)pass, st->noise_rows - 1) * V;
-  float v[NVT], qn[NVT];
 #pragma unroll
   for (int j = 0; j < NVT; ++j) {
     const int i = j * 256 + tid;
-    v[j] = (i < V) ? lg[i] : -INFINITY;
+    if (i >= V) v[j] = -INFINITY;
     qn[j] = (nz != nullptr && i < V) ? nz[i] : 1.f;
   }
   const float temp = st->temperature;
