@@ -728,27 +728,40 @@ __global__ __launch_bounds__(NW * KG * 64) void mfma_attn_kernel(const bf16* __r
         accS[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], accS[sub], 0, 0, 0);
       }
     }
-    // mask + running max (register v of half hh holds key (v&3) + 8(v>>2) + 4hh of the sub-tile)
+    // mask + running max (register v of half hh holds key (v&3) + 8(v>>2) + 4hh of the sub-tile).  A tile every
+    // query of the wave sees in full needs no per-element mask (wave-uniform test): all but the last tile of an
+    // unmasked (NAR) stage, and every tile left of the diagonal under the prefix mask.
     float mloc = -INFINITY;
+    if (__builtin_amdgcn_ballot_w64(kt + 64 > limit) == 0) {
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+      for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int kgi = kt + sub * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
-        const float sv = (kgi < limit) ? accS[sub][v] : -INFINITY;
-        accS[sub][v] = sv;
-        mloc = fmaxf(mloc, sv);
-      }
+        for (int v = 0; v < 16; ++v) mloc = fmaxf(mloc, accS[sub][v]);
+    } else {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int kgi = kt + sub * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
+          const float sv = (kgi < limit) ? accS[sub][v] : -INFINITY;
+          accS[sub][v] = sv;
+          mloc = fmaxf(mloc, sv);
+        }
+    }
     mloc = fmaxf(mloc, xor32_f(mloc));
     const float m_new = fmaxf(m_run, mloc);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: exp(-inf - 0) = 0
-    const float corr = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);
+    // rescale the running sums only when some query's maximum moved (wave-uniform test; the factor is exactly 1
+    // otherwise): after the first few key tiles it rarely does
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+      const float corr = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);
+      l_run *= corr;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) accO[t][v] *= corr;
+    }
     m_run = m_new;
-    l_run *= corr;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) accO[t][v] *= corr;
     // P^T = exp(S^T - m), cast to bf16 in accumulator order = B fragments of the next product
     bf16x8_t pf[2][2];
 #pragma unroll
