@@ -113,6 +113,8 @@ struct vx_engine {
   float *pn_a = nullptr, *pn_b = nullptr, *pn_h1 = nullptr, *pn_h2 = nullptr, *pn_text = nullptr, *d_zero = nullptr;
   float *ar_e = nullptr, *ar_h1 = nullptr, *ar_h2 = nullptr;
   float* convT[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  float* slab = nullptr;                              // split-K slabs of the N = d row GEMMs (4 x slab_rows x d fp32)
+  int slab_rows = 0;
   bool seg_text_on = false;                           // true only while a batched prefill runs its stack
   long long *bp_text = nullptr, *bp_audio = nullptr;  // id staging of the batched prefill
   size_t cap_audio = 0, cap_text = 0;                 // rows the id / yemb / logits staging buffers hold
@@ -305,6 +307,10 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   VXC(dalloc_t(e, &e->ids_samples, (size_t)c.max_audio));
   VXC(dalloc_t(e, &e->d_codes, (size_t)c.max_audio * 8));
   e->cap_audio = c.max_audio; e->cap_text = c.max_text;
+  if (e->bf16 && !(c.flags & VX_FLAG_SIMPLE_ROWS)) {
+    e->slab_rows = e->n_max < 4095 ? e->n_max : 4095;
+    VXC(dalloc_t(e, &e->slab, (size_t)4 * e->slab_rows * dmax));
+  }
   if (c.flags & VX_FLAG_PRENET) {
     VXC(dalloc_t(e, &e->pn_a, n * dmax));
     VXC(dalloc_t(e, &e->pn_b, n * dmax));
@@ -553,10 +559,12 @@ static int gemm_rows(vx_engine* e, const void* A, const void* Wt, const float* b
   return gemm_rows_t<float>(false, (const float*)A, (const float*)Wt, bias, C, M, N, K, epi, out_f32, e->es);
 }
 
+// fold: the split-K slabs (and bias) of the GEMM in front of this norm, added to x first (rows_kernels.hpp)
+struct Fold { const float* part = nullptr; int nsplit = 0; size_t stride = 0; const float* bias = nullptr; };
 static int ln_rows(vx_engine* e, const float* x, const float* g, const float* b, const float* aw, const float* ab,
-                   void* out, int rows, int d, float* xout = nullptr) {
-  if (e->bf16) layernorm_rows_kernel<bf16><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (bf16*)out, rows, d, xout);
-  else layernorm_rows_kernel<float><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (float*)out, rows, d, xout);
+                   void* out, int rows, int d, float* xout = nullptr, Fold f = Fold()) {
+  if (e->bf16) layernorm_rows_kernel<bf16><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (bf16*)out, rows, d, xout, f.part, f.nsplit, f.stride, f.bias);
+  else layernorm_rows_kernel<float><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (float*)out, rows, d, xout, f.part, f.nsplit, f.stride, f.bias);
   return VX_OK;
 }
 // fp32 linear layer on rows (prenets keep fp32 weights in every precision mode): C = [relu](A W^T + b)
@@ -609,11 +617,24 @@ static int attn_rows(vx_engine* e, const void* qkv, void* out, int M, int d, int
 // One encoder stack over M rows held in e->X (valle.py:1035-1038 / 1125-1127).  `ada_stage` < 0:
 // plain LayerNorm (AR); otherwise the stage's AdaLN vectors.  If kv_layer0 is non-null the K/V
 // rows are also scattered into the decode cache.
+static int split_for(int K) {  // K slices of the split-K GEMMs: a multiple of the 64-wide K tile each
+  for (int sp = 4; sp > 1; sp >>= 1)
+    if (K % (64 * sp) == 0) return sp;
+  return 1;
+}
+
 static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int d, int H, int text_len, int ada_stage,
                      bool fill_cache, char* kv_base = nullptr) {
   if (kv_base == nullptr) kv_base = (char*)e->kv;
   const bool post = e->cfg.flags & VX_FLAG_POST_NORM;
   const size_t kv_layer = (size_t)2 * H * e->ctx_max * 64 * e->esz;
+  // The two N = d GEMMs of a layer (out-projection, FFN2) at M ~ 1k rows: 128^2 tiles alone are 72 workgroups, so K is
+  // split over 2-4 workgroups per tile, every slice writes an fp32 slab, and the LayerNorm that follows the GEMM anyway
+  // adds bias + slabs to x in a fixed order.  Larger M (batched rows) has enough tiles and adds in the GEMM epilogue.
+  const bool splitk = use_mfma(e) && M < 4096 && M <= e->slab_rows && d % 128 == 0 && d >= 128;
+  const size_t sstride = (size_t)M * d;
+  const int sp_d = split_for(d), sp_ff = split_for(4 * d);
+  Fold pend;  // FFN2 slabs of the previous layer, folded by the next norm (pre-norm) or by the trailing fold pass
   for (size_t li = 0; li < layers.size(); ++li) {
     const LayerW& l = layers[li];
     const float *aw1 = nullptr, *ab1 = nullptr, *aw2 = nullptr, *ab2 = nullptr;
@@ -623,7 +644,7 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
     }
     // pre-norm (transformer.py:296-302): Hn = norm1(x).  post-norm (303-308): the block reads x itself; Hn already
     // holds it in operand precision from the previous layer's norm2 (layer 0: cast here)
-    if (!post) VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d));
+    if (!post) { VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d, nullptr, pend)); pend = Fold(); }
     else if (li == 0) VXC(cast_rows(e, e->X, e->Hn, (size_t)M * d));
     VXC(gemm_rows(e, e->Hn, l.in_w, l.in_b, e->QKV, M, 3 * d, d, GE_BIAS, false, use_mfma(e)));
     if (fill_cache && e->nseg > 0) {  // batched prefill: segment z -> slot z
@@ -637,13 +658,28 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
       else kv_scatter_kernel<float><<<M, 256, 0, e->es>>>((const float*)e->QKV, (float*)kc, (float*)vc, M, d, 64, e->ctx_max);
     }
     VXC(attn_rows(e, e->QKV, e->ATT, M, d, H, text_len));
-    VXC(gemm_rows(e, e->ATT, l.out_w, l.out_b, e->X, M, d, d, GE_RESID, true));
-    if (!post) VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn, M, d));
-    else VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d, e->X));  // x = norm1(x + sa(x))
+    Fold fo;  // out-projection: x += out_proj(attn), folded into the norm that follows when split
+    if (splitk) {
+      VXC(mfma_gemm_partial((const bf16*)e->ATT, (const bf16*)l.out_w, e->slab, M, d, d, sp_d, e->es));
+      fo.part = e->slab; fo.nsplit = sp_d; fo.stride = sstride; fo.bias = l.out_b;
+    } else {
+      VXC(gemm_rows(e, e->ATT, l.out_w, l.out_b, e->X, M, d, d, GE_RESID, true));
+    }
+    if (!post) VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn, M, d, nullptr, fo));
+    else VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d, e->X, fo));  // x = norm1(x + sa(x))
     VXC(gemm_rows(e, e->Hn, l.w1, l.b1, e->FF, M, 4 * d, d, GE_RELU, false));
-    VXC(gemm_rows(e, e->FF, l.w2, l.b2, e->X, M, d, 4 * d, GE_RESID, true));
-    if (post) VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn, M, d, e->X));  // x = norm2(x + ff(x))
+    Fold ff;
+    if (splitk) {
+      VXC(mfma_gemm_partial((const bf16*)e->FF, (const bf16*)l.w2, e->slab, M, d, 4 * d, sp_ff, e->es));
+      ff.part = e->slab; ff.nsplit = sp_ff; ff.stride = sstride; ff.bias = l.b2;
+    } else {
+      VXC(gemm_rows(e, e->FF, l.w2, l.b2, e->X, M, d, 4 * d, GE_RESID, true));
+    }
+    if (post) VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn, M, d, e->X, ff));  // x = norm2(x + ff(x))
+    else pend = ff;
   }
+  if (pend.part != nullptr)  // the last layer's FFN2 slabs: x += b2 + slabs (no norm: the caller applies the final one)
+    VXC(ln_rows(e, e->X, nullptr, nullptr, nullptr, nullptr, nullptr, M, d, nullptr, pend));
   HIPC(hipGetLastError());
   return VX_OK;
 }

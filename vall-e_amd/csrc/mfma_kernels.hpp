@@ -25,7 +25,13 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                         const float* __restrict__ bias, void* __restrict__ Cv, int M,
-                                                        int N, int K, bf16* __restrict__ vt, int vt_n0, int vt_ld) {
+                                                        int N, int K, bf16* __restrict__ vt, int vt_n0, int vt_ld, int ld) {
+  // K = the K range this workgroup multiplies, ld = row stride of A and W.  gridDim.z > 1: split K across
+  // workgroups, slice z covers columns [z K, (z+1) K) and writes its own (M, N) fp32 slab (GE_PLAIN, OUT_F32): the
+  // LayerNorm that follows the GEMM anyway adds bias + slabs in a fixed order (deterministic, no atomics).
+  A += (size_t)blockIdx.z * K;
+  W += (size_t)blockIdx.z * K;
+  if (OUT_F32) Cv = reinterpret_cast<float*>(Cv) + (size_t)blockIdx.z * M * N;
   constexpr int BM = 128, BN = 128, BK = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // layout: [buf][A|W][128 rows * 128 B]
@@ -53,8 +59,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = tid + i * 256, row = q >> 3, c = q & 7;
-      ra[S][i] = ld16(A + (size_t)min(m0 + row, M - 1) * K + k0 + c * 8);
-      rw[S][i] = ld16(W + (size_t)min(n0 + row, N - 1) * K + k0 + c * 8);
+      ra[S][i] = ld16(A + (size_t)min(m0 + row, M - 1) * ld + k0 + c * 8);
+      rw[S][i] = ld16(W + (size_t)min(n0 + row, N - 1) * ld + k0 + c * 8);
     }
   };
   auto lstore = [&](auto SET, int buf) {
@@ -565,7 +571,7 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
       (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
       attr_done = true;                                                                                                 \
     }                                                                                                                   \
-    mfma_gemm_kernel<E, F><<<grid, 256, 65536, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld);                          \
+    mfma_gemm_kernel<E, F><<<grid, 256, 65536, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, K);                       \
   } while (0)
     if (epi == GE_RESID) MG(GE_RESID, true);
     else if (epi == GE_PLAIN) MG(GE_PLAIN, true);
@@ -607,6 +613,19 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
     else WG(GE_RELU, false, 1);
   }
 #undef WG
+  return 0;
+}
+
+// C_z = A[:, zK/s:(z+1)K/s] . W[:, same]^T for z < splits, each into its own fp32 (M, N) slab: the N = d GEMMs
+// (out-projection, FFN2) at M ~ 1k rows, where 128^2 tiles alone give 72 workgroups.  splits in {1,2,4}.
+static inline int mfma_gemm_partial(const bf16* A, const bf16* W, float* slabs, int M, int N, int K, int splits, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<GE_PLAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr_done = true;
+  }
+  dim3 grid(N / 128, (M + 127) / 128, splits);
+  mfma_gemm_kernel<GE_PLAIN, true><<<grid, 256, 65536, s>>>(A, W, nullptr, slabs, M, N, K / splits, nullptr, 0, 0, K);
   return 0;
 }
 

@@ -103,7 +103,11 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, con
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ ada_w,
                                                              const float* __restrict__ ada_b, OT* __restrict__ out,
-                                                             int rows, int d, float* xout = nullptr) {
+                                                             int rows, int d, float* xout = nullptr,
+                                                             const float* __restrict__ part = nullptr, int nsplit = 0,
+                                                             size_t part_stride = 0, const float* __restrict__ pbias = nullptr) {
+  // part != nullptr: the row first receives the preceding split-K GEMM, x += pbias + sum_z part[z] (fixed order); the
+  // sum is written back to x unless xout redirects the normalised row there (post-norm).  out == nullptr: fold only.
   // xout (post-norm layers, transformer.py:303-308): the normalised row also replaces the residual stream; it may
   // alias x (every element is read into registers by its own lane before anything is stored)
   constexpr int MAXV = 8;  // d <= 2048
@@ -117,8 +121,21 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, con
   for (int i = 0; i < MAXV; ++i) {
     const int k = (i * 64 + lane) * 4;
     v[i] = (k < d) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (part != nullptr && k < d) {
+      float4 t = *reinterpret_cast<const float4*>(pbias + k);
+      float4 p[4];  // nsplit <= 4; all loads go out together (clamped slab index, masked sum)
+#pragma unroll
+      for (int z = 0; z < 4; ++z)
+        p[z] = *reinterpret_cast<const float4*>(part + (size_t)min(z, nsplit - 1) * part_stride + (size_t)r * d + k);
+#pragma unroll
+      for (int z = 0; z < 4; ++z)
+        if (z < nsplit) { t.x += p[z].x; t.y += p[z].y; t.z += p[z].z; t.w += p[z].w; }
+      v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+      if (xout == nullptr || out == nullptr) *reinterpret_cast<float4*>(const_cast<float*>(xr) + k) = v[i];
+    }
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
+  if (out == nullptr) return;  // fold-only pass (wave-uniform)
   const float mean = wave_sum(s) / (float)d;
   float ss = 0.f;
 #pragma unroll
