@@ -1,13 +1,13 @@
 """Non-asserting GPU diagnostics: prints error metrics of every kernel / engine mode against the
 oracle, as JSON lines, so tolerances in the tests are set from measurements.  Run on the box:
-    python tests/gpu_diag.py > gpurun_out/diag.jsonl"""
+    python tests/probes/gpu_diag.py > gpurun_out/diag.jsonl"""
 import json
 import os
 import sys
 import time
 import traceback
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402

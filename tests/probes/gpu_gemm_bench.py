@@ -1,6 +1,6 @@
 """Scratch: stand-alone timing of the MFMA GEMM variants through vx_op_gemm (bf16), TFLOP/s vs shape."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as ge

@@ -1,6 +1,6 @@
 """Scratch: fixed cost vs per-K-step cost of the row GEMMs at the batch-1 NAR shape (M = 1025)."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as ge

@@ -1,6 +1,6 @@
 """Scratch: per-layer AR step time vs model size (does Infinity-Cache residency of the weights help?)."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import __graft_entry__ as ge

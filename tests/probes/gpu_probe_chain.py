@@ -1,6 +1,6 @@
 """Scratch probe (not a test): cost of one dependent GEMV stage inside a single persistent launch."""
 import json, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import valle_amd  # noqa
 from valle_amd.engine import stage_chain, launch_floor
 

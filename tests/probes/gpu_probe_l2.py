@@ -1,6 +1,6 @@
 """Scratch probe (not a test): L2 -> CU fill rate vs workgroups per CU, waves and loads in flight."""
 import json, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import valle_amd  # noqa
 from valle_amd.engine import l2_fill
 

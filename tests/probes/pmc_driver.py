@@ -1,6 +1,6 @@
 """Torch-free driver of the C ABI for counter collection (rocprofv3 --pmc crashes inside torch's
 start-up on this image): random weights of the cfg1 geometry, one prefill, N eager AR steps.
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -- python3 tests/pmc_driver.py 40
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -- python3 tests/probes/pmc_driver.py 40
 """
 import ctypes as C
 import os
@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lib = C.CDLL(os.path.join(ROOT, "vall-e_amd", "csrc", "libvallex.so"))
 lib.vx_last_error.restype = C.c_char_p
 NSTEP = int(sys.argv[1]) if len(sys.argv) > 1 else 40

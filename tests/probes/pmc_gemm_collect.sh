@@ -1,6 +1,6 @@
 #!/bin/bash
 # Scratch: PMC passes over one GEMM shape (separate rocprofv3 runs per counter group, kernel-trace only).
-# usage: tests/pmc_gemm_collect.sh OUTDIR M N K
+# usage: tests/probes/pmc_gemm_collect.sh OUTDIR M N K
 out=$1; M=$2; N=$3; K=$4
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
@@ -13,7 +13,7 @@ for c in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
          "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
          "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
   i=$((i+1))
-  timeout -k 10 120 rocprofv3 --pmc $c --kernel-trace -d $out/p$i -o g --output-format csv -- python3 tests/pmc_gemm_driver.py $M $N $K 3 > $out/p$i.log 2>&1 || echo "fail group $i: $c"
+  timeout -k 10 120 rocprofv3 --pmc $c --kernel-trace -d $out/p$i -o g --output-format csv -- python3 tests/probes/pmc_gemm_driver.py $M $N $K 3 > $out/p$i.log 2>&1 || echo "fail group $i: $c"
 done
 python3 - "$out" <<'PY'
 import csv, glob, collections, sys, json

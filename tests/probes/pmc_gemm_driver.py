@@ -1,10 +1,10 @@
 """Torch-free driver: one bf16 GEMM through vx_op_gemm for rocprofv3 --pmc (traffic / MFMA counters).
-usage: python3 tests/pmc_gemm_driver.py M N K [iters]   (VX_GEMM_ALG selects the kernel)"""
+usage: python3 tests/probes/pmc_gemm_driver.py M N K [iters]   (VX_GEMM_ALG selects the kernel)"""
 import ctypes as C
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 hip = C.CDLL("libamdhip64.so")
 lib = C.CDLL(os.path.join(ROOT, "vall-e_amd", "csrc", "libvallex.so"))
 lib.vx_last_error.restype = C.c_char_p

@@ -1,5 +1,5 @@
-"""Summarise rocprofv3 --pmc counter_collection.csv files of tests/pmc_driver.py into per-AR-step sums.
-usage: python tests/pmc_summarize.py OUT.json NAME=dir [NAME=dir ...]"""
+"""Summarise rocprofv3 --pmc counter_collection.csv files of tests/probes/pmc_driver.py into per-AR-step sums.
+usage: python tests/probes/pmc_summarize.py OUT.json NAME=dir [NAME=dir ...]"""
 import collections
 import csv
 import glob

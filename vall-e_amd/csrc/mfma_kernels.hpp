@@ -20,7 +20,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 // XOR-swizzled by ((row >> 1) & 7) so the 16 rows a ds_read_b128 lane group touches fall on 16
 // distinct 16-byte slots of the 256-byte bank row (T2).  The lane groups of ds_read_b128 are NOT 16 consecutive
 // lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...): `row & 7` looks right on paper and measures 2-way
-// (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE); tests/lds_conflicts.py checks a swizzle against the groups.  Global->register->LDS staging with
+// (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE); tests/probes/lds_conflicts.py checks a swizzle against the groups.  Global->register->LDS staging with
 // the next tile's global loads issued before the current tile's MFMAs (T14 split).
 template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
