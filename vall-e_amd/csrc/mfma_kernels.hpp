@@ -78,21 +78,25 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
   auto compute = [&](int cur) {
     const unsigned char* ba = lds + cur * 32768;
     const unsigned char* bw = ba + 16384;
+    // all 16 fragment reads of the K tile first, then the 16 MFMAs behind counted lgkmcnt waits: with one wave per SIMD
+    // nothing else hides LDS latency, and read-4 / wait / multiply-4 per 16 of K exposed it four times per tile
+    bf16x8_t fa[4][2], fb[4][2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8_t fa[2], fb[2];
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = wm * 64 + i * 32 + r;
-        fa[i] = *reinterpret_cast<const bf16x8_t*>(ba + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4));
+        fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(ba + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4));
         const int col = wn * 64 + i * 32 + r;
-        fb[i] = *reinterpret_cast<const bf16x8_t*>(bw + col * 128 + (((ks * 2 + h) ^ ((col >> 1) & 7)) << 4));
+        fb[ks][i] = *reinterpret_cast<const bf16x8_t*>(bw + col * 128 + (((ks * 2 + h) ^ ((col >> 1) & 7)) << 4));
       }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
