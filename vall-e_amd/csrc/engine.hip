@@ -563,8 +563,9 @@ static int gemm_rows(vx_engine* e, const void* A, const void* Wt, const float* b
 struct Fold { const float* part = nullptr; int nsplit = 0; size_t stride = 0; const float* bias = nullptr; };
 static int ln_rows(vx_engine* e, const float* x, const float* g, const float* b, const float* aw, const float* ab,
                    void* out, int rows, int d, float* xout = nullptr, Fold f = Fold()) {
-  if (e->bf16) layernorm_rows_kernel<bf16><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (bf16*)out, rows, d, xout, f.part, f.nsplit, f.stride, f.bias);
-  else layernorm_rows_kernel<float><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (float*)out, rows, d, xout, f.part, f.nsplit, f.stride, f.bias);
+  // d <= 1024 in the engine (vx_create): 4 float4 per lane
+  if (e->bf16) layernorm_rows_kernel<bf16, 4><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (bf16*)out, rows, d, xout, f.part, f.nsplit, f.stride, f.bias);
+  else layernorm_rows_kernel<float, 4><<<(rows + 3) / 4, 256, 0, e->es>>>(x, g, b, aw, ab, (float*)out, rows, d, xout, f.part, f.nsplit, f.stride, f.bias);
   return VX_OK;
 }
 // fp32 linear layer on rows (prenets keep fp32 weights in every precision mode): C = [relu](A W^T + b)
@@ -1372,6 +1373,10 @@ static int ensure_rows(vx_engine* e, size_t rows, size_t audio_rows, size_t text
   VXC(regrow(&e->VT, dmax * (size_t)e->vt_ld * 2));
   HIPC(hipMemset(e->VT, 0, dmax * (size_t)e->vt_ld * 2));
   HIPC(hipMemset(e->X, 0, rows * dmax * 4));
+  if (e->slab != nullptr) {  // keep the split-K path available for concatenated rows below the 256^2 threshold
+    e->slab_rows = rows < 4095 ? (int)rows : 4095;
+    VXC(regrow((void**)&e->slab, (size_t)4 * e->slab_rows * dmax * 4));
+  }
   VXC(regrow((void**)&e->yemb, audio_rows * dmax * 4));
   VXC(regrow((void**)&e->nar_logits, audio_rows * 1024 * 4));
   VXC(regrow((void**)&e->ids_text, text_rows * 8));
@@ -1529,8 +1534,13 @@ extern "C" int vx_op_layernorm(int32_t prec, const float* x, const float* gamma,
                                const float* ada_b, void* out, int32_t rows, int32_t d, void* stream) {
   if (d % 4 || d > 2048) return fail(VX_ERR_UNSUPPORTED, "layernorm: d=%d", d);
   hipStream_t s = (hipStream_t)stream;
-  if (prec == VX_PREC_BF16) layernorm_rows_kernel<bf16><<<(rows + 3) / 4, 256, 0, s>>>(x, gamma, beta, ada_w, ada_b, (bf16*)out, rows, d);
-  else layernorm_rows_kernel<float><<<(rows + 3) / 4, 256, 0, s>>>(x, gamma, beta, ada_w, ada_b, (float*)out, rows, d);
+  if (d <= 1024) {
+    if (prec == VX_PREC_BF16) layernorm_rows_kernel<bf16, 4><<<(rows + 3) / 4, 256, 0, s>>>(x, gamma, beta, ada_w, ada_b, (bf16*)out, rows, d);
+    else layernorm_rows_kernel<float, 4><<<(rows + 3) / 4, 256, 0, s>>>(x, gamma, beta, ada_w, ada_b, (float*)out, rows, d);
+  } else {
+    if (prec == VX_PREC_BF16) layernorm_rows_kernel<bf16, 8><<<(rows + 3) / 4, 256, 0, s>>>(x, gamma, beta, ada_w, ada_b, (bf16*)out, rows, d);
+    else layernorm_rows_kernel<float, 8><<<(rows + 3) / 4, 256, 0, s>>>(x, gamma, beta, ada_w, ada_b, (float*)out, rows, d);
+  }
   HIPC(hipGetLastError());
   return VX_OK;
 }

@@ -47,6 +47,12 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+  // the epilogue's bias values, loaded now: fetched after the K loop they are one more exposed memory round trip
+  float bias_r[2] = {0.f, 0.f};
+  if (EPI != GE_PLAIN) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bias_r[j] = bias[min(n0 + wn * 64 + j * 32 + r, N - 1)];
+  }
 
   // staging: 1024 16-byte chunks per operand tile, 4 per thread; THREE register sets so that three
   // K tiles of global loads are in flight while one is being multiplied (at M ~ 1k rows there is
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int nl = wn * 64 + j * 32 + r;
-      const float bv = (EPI != GE_PLAIN) ? bias[n0 + nl] : 0.f;
+      const float bv = bias_r[j];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wn * 64 + j * 32 + r;
-      const float bv = (EPI != GE_PLAIN && n < N) ? bias[n] : 0.f;
+      const float bv = bias_r[j];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_weight_relayout_kernel(const float* 
 
 // (Adaptive)LayerNorm, one wave per row: out = [w *] (LN(x) * gamma + beta) [+ b]
 // (modules/transformer.py:57-74, 93-108).  OT = float or bf16 (the GEMM A-operand type).
-template <typename OT>
+template <typename OT, int MAXV>  // MAXV float4 per lane: d <= 256 * MAXV
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ ada_w,
@@ -109,63 +109,75 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, con
   // part != nullptr: the row first receives the preceding split-K GEMM, x += pbias + sum_z part[z] (fixed order); the
   // sum is written back to x unless xout redirects the normalised row there (post-norm).  out == nullptr: fold only.
   // xout (post-norm layers, transformer.py:303-308): the normalised row also replaces the residual stream; it may
-  // alias x (every element is read into registers by its own lane before anything is stored)
-  constexpr int MAXV = 8;  // d <= 2048
+  // alias x (every element is read into registers by its own lane before anything is stored).
+  // Every load of the kernel (row, slabs, affine and AdaLN vectors) is issued before the first reduction: the kernel
+  // is one memory round trip, not one per phase.
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const float* xr = x + (size_t)r * d;
-  float4 v[MAXV];
-  float s = 0.f;
+  const bool fold = part != nullptr, norm = out != nullptr, ada = ada_w != nullptr;  // wave-uniform
+  float4 v[MAXV], g[MAXV], b[MAXV], w[MAXV], c[MAXV];
+  int kk[MAXV];
+  bool ok[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int k = (i * 64 + lane) * 4;
-    v[i] = (k < d) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (part != nullptr && k < d) {
-      float4 t = *reinterpret_cast<const float4*>(pbias + k);
+    ok[i] = k < d;
+    kk[i] = ok[i] ? k : 0;  // clamped: the loads below are unconditional
+    v[i] = *reinterpret_cast<const float4*>(xr + kk[i]);
+    if (norm) {
+      g[i] = *reinterpret_cast<const float4*>(gamma + kk[i]);
+      b[i] = *reinterpret_cast<const float4*>(beta + kk[i]);
+      if (ada) {
+        w[i] = *reinterpret_cast<const float4*>(ada_w + kk[i]);
+        c[i] = *reinterpret_cast<const float4*>(ada_b + kk[i]);
+      }
+    }
+  }
+  if (fold) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      float4 t = *reinterpret_cast<const float4*>(pbias + kk[i]);
       float4 p[4];  // nsplit <= 4; all loads go out together (clamped slab index, masked sum)
 #pragma unroll
       for (int z = 0; z < 4; ++z)
-        p[z] = *reinterpret_cast<const float4*>(part + (size_t)min(z, nsplit - 1) * part_stride + (size_t)r * d + k);
+        p[z] = *reinterpret_cast<const float4*>(part + (size_t)min(z, nsplit - 1) * part_stride + (size_t)r * d + kk[i]);
 #pragma unroll
       for (int z = 0; z < 4; ++z)
         if (z < nsplit) { t.x += p[z].x; t.y += p[z].y; t.z += p[z].z; t.w += p[z].w; }
       v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
-      if (xout == nullptr || out == nullptr) *reinterpret_cast<float4*>(const_cast<float*>(xr) + k) = v[i];
+      if (ok[i] && (xout == nullptr || !norm)) *reinterpret_cast<float4*>(const_cast<float*>(xr) + kk[i]) = v[i];
     }
-    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
-  if (out == nullptr) return;  // fold-only pass (wave-uniform)
+  if (!norm) return;  // fold-only pass
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) s += ok[i] ? (v[i].x + v[i].y) + (v[i].z + v[i].w) : 0.f;
   const float mean = wave_sum(s) / (float)d;
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int k = (i * 64 + lane) * 4;
-    if (k < d) {
-      const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
-      ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
+    const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+    ss += ok[i] ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
   }
   const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)d + LN_EPS);
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int k = (i * 64 + lane) * 4;
-    if (k < d) {
-      const float4 g = *reinterpret_cast<const float4*>(gamma + k);
-      const float4 b = *reinterpret_cast<const float4*>(beta + k);
-      float o[4] = {(v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
-                    (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w};
-      if (ada_w != nullptr) {
-        const float4 w = *reinterpret_cast<const float4*>(ada_w + k);
-        const float4 c = *reinterpret_cast<const float4*>(ada_b + k);
-        o[0] = __fadd_rn(__fmul_rn(w.x, o[0]), c.x); o[1] = __fadd_rn(__fmul_rn(w.y, o[1]), c.y);
-        o[2] = __fadd_rn(__fmul_rn(w.z, o[2]), c.z); o[3] = __fadd_rn(__fmul_rn(w.w, o[3]), c.w);
-      }
-      OT* op = out + (size_t)r * d + k;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) op[j] = from_f32<OT>(o[j]);
-      if (xout != nullptr) *reinterpret_cast<float4*>(xout + (size_t)r * d + k) = make_float4(o[0], o[1], o[2], o[3]);
+    if (!ok[i]) continue;
+    float o[4] = {(v[i].x - mean) * rstd * g[i].x + b[i].x, (v[i].y - mean) * rstd * g[i].y + b[i].y,
+                  (v[i].z - mean) * rstd * g[i].z + b[i].z, (v[i].w - mean) * rstd * g[i].w + b[i].w};
+    if (ada) {
+      o[0] = __fadd_rn(__fmul_rn(w[i].x, o[0]), c[i].x); o[1] = __fadd_rn(__fmul_rn(w[i].y, o[1]), c[i].y);
+      o[2] = __fadd_rn(__fmul_rn(w[i].z, o[2]), c[i].z); o[3] = __fadd_rn(__fmul_rn(w[i].w, o[3]), c[i].w);
     }
+    union { OT e[4]; uint2 u2; float4 f4; } pk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pk.e[j] = from_f32<OT>(o[j]);
+    OT* op = out + (size_t)r * d + kk[i];
+    if (sizeof(OT) == 2) *reinterpret_cast<uint2*>(op) = pk.u2;
+    else *reinterpret_cast<float4*>(op) = pk.f4;
+    if (xout != nullptr) *reinterpret_cast<float4*>(xout + (size_t)r * d + kk[i]) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
