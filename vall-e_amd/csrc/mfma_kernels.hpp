@@ -253,21 +253,24 @@ __global__ __launch_bounds__(256) void wgemm_kernel(const bf16* __restrict__ A, 
     auto compute = [&](int cur) {
       const unsigned char* ba = my + cur * 16384;
       const unsigned char* bw = ba + 8192;
+      // all 16 fragment reads first (one wave per SIMD: a read / multiply chain exposes the LDS latency per k-step)
+      bf16x8_t fa[4][2], fb[4][2];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8_t fa[2], fb[2];
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int row = i * 32 + r;
           const int off = row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4);
-          fa[i] = *reinterpret_cast<const bf16x8_t*>(ba + off);
-          fb[i] = *reinterpret_cast<const bf16x8_t*>(bw + off);
+          fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(ba + off);
+          fb[ks][i] = *reinterpret_cast<const bf16x8_t*>(bw + off);
         }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
