@@ -681,7 +681,8 @@ __global__ __launch_bounds__(NW * KG * 64) void mfma_attn_kernel(const bf16* __r
     vt += r0;
   }
   constexpr int CPT = 512 * KG / NT;  // 16-byte chunks per thread per operand per iteration (KG tiles of 64 rows x 8 chunks)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][KG][2][64 * 128];  // [buf][key group][K | V^T][row * 128 B]
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];  // [buf][key group][K | V^T][64 rows * 128 B]
+  auto ldsp = [&](int buf, int g, int kv) { return lds_raw + (size_t)(((buf * KG + g) * 2 + kv)) * 8192; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qw = wave % NW, kg = wave / NW;
   const int r = lane & 31, hh = lane >> 5;
@@ -727,8 +728,8 @@ __global__ __launch_bounds__(NW * KG * 64) void mfma_attn_kernel(const bf16* __r
     for (int i = 0; i < CPT; ++i) {
       const int q = tid + i * NT, g = q >> 9, row = (q >> 3) & 63, c = q & 7;
       const int off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
-      *reinterpret_cast<uint4*>(&lds[buf][g][0][off]) = rk[i];
-      *reinterpret_cast<uint4*>(&lds[buf][g][1][off]) = rv[i];
+      *reinterpret_cast<uint4*>(ldsp(buf, g, 0) + off) = rk[i];
+      *reinterpret_cast<uint4*>(ldsp(buf, g, 1) + off) = rv[i];
     }
   };
 
@@ -745,8 +746,8 @@ __global__ __launch_bounds__(NW * KG * 64) void mfma_attn_kernel(const bf16* __r
   for (int it = 0; it < niter; ++it) {
     const int cur = it & 1, kt = (it * KG + kg) * 64;
     if (it + 1 < niter) gload(it + 1);
-    const unsigned char* kb = &lds[cur][kg][0][0];
-    const unsigned char* vb = &lds[cur][kg][1][0];
+    const unsigned char* kb = ldsp(cur, kg, 0);
+    const unsigned char* vb = ldsp(cur, kg, 1);
     // S^T for the two 32-key sub-tiles
     f32x16_t accS[2];
 #pragma unroll
@@ -824,12 +825,12 @@ __global__ __launch_bounds__(NW * KG * 64) void mfma_attn_kernel(const bf16* __r
     __syncthreads();
   }
   float l_tot = l_run + xor32_f(l_run);
-  if constexpr (KG == 2) {
-    // merge the two key groups of every query slice: group 1 parks (m, l, O^T) in LDS (the operand buffers are free
-    // after the loop's last barrier), group 0 rescales both to the common maximum and finishes
-    float* park = reinterpret_cast<float*>(&lds[0][0][0][0]) + (size_t)qw * 64 * 36;  // 34 used floats per lane, stride 36
-    if (kg == 1) {
-      float* p = park + lane * 36;
+  if constexpr (KG > 1) {
+    // merge the key groups of every query slice: groups 1.. park (m, l, O^T) in LDS (the operand buffers are free after
+    // the loop's last barrier), group 0 rescales everything to the common maximum, in group order, and finishes
+    float* park = reinterpret_cast<float*>(lds_raw);  // [group - 1][slice][lane][36]: 34 used floats per lane
+    if (kg > 0) {
+      float* p = park + ((size_t)((kg - 1) * NW + qw) * 64 + lane) * 36;
       p[0] = m_run; p[1] = l_tot;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -837,16 +838,20 @@ __global__ __launch_bounds__(NW * KG * 64) void mfma_attn_kernel(const bf16* __r
         for (int v = 0; v < 16; v += 4) *reinterpret_cast<float4*>(p + 4 + t * 16 + v) = make_float4(accO[t][v], accO[t][v + 1], accO[t][v + 2], accO[t][v + 3]);
     }
     __syncthreads();
-    if (kg == 1) return;
-    const float* p = park + lane * 36;
-    const float m1 = p[0], l1 = p[1];
-    const float mm = fmaxf(m_run, m1);
-    const float f0 = (m_run == -INFINITY) ? 0.f : __expf(m_run - mm), f1 = (m1 == -INFINITY) ? 0.f : __expf(m1 - mm);
-    l_tot = l_tot * f0 + l1 * f1;
+    if (kg > 0) return;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int g = 1; g < KG; ++g) {
+      const float* p = park + ((size_t)((g - 1) * NW + qw) * 64 + lane) * 36;
+      const float m1 = p[0], l1 = p[1];
+      const float mm = fmaxf(m_run, m1);
+      const float f0 = (m_run == -INFINITY) ? 0.f : __expf(m_run - mm), f1 = (m1 == -INFINITY) ? 0.f : __expf(m1 - mm);
+      l_tot = l_tot * f0 + l1 * f1;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) accO[t][v] = accO[t][v] * f0 + p[4 + t * 16 + v] * f1;
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) accO[t][v] = accO[t][v] * f0 + p[4 + t * 16 + v] * f1;
+      m_run = mm;
+    }
   }
   if (qvalid) {
     const float inv = 1.0f / l_tot;
@@ -879,10 +884,21 @@ static inline int mfma_attn_dispatch(const bf16* qkv, const bf16* vt, int vt_ld,
   const int rows = seg_start ? max_seg_len : M;
   dim3 grid((rows + 32 * NW - 1) / (32 * NW), H, seg_start ? nseg : 1);
   // fewer than ~2 workgroups per CU: split the keys over two wave groups inside the workgroup (4 waves = all 4 SIMDs)
-  if ((long long)grid.x * grid.y * grid.z < 512)
-    mfma_attn_kernel<NW, 2><<<grid, NW * 2 * 64, 0, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
+  static const int kgsel = [] { const char* v = getenv("VX_ATTN_KG"); return v ? atoi(v) : 0; }();  // A/B runs
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)mfma_attn_kernel<NW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)mfma_attn_kernel<NW, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    attr_done = true;
+  }
+  const long long nwg = (long long)grid.x * grid.y * grid.z;
+  const int kg = kgsel ? kgsel : (nwg < 512 ? 2 : 1);  // 4 groups measured slower than 2 at batch-1 NAR (10.7 vs 10.3 ms)
+  if (kg == 4)
+    mfma_attn_kernel<NW, 4><<<grid, NW * 4 * 64, 131072, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
+  else if (kg == 2)
+    mfma_attn_kernel<NW, 2><<<grid, NW * 2 * 64, 65536, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
   else
-    mfma_attn_kernel<NW, 1><<<grid, NW * 64, 0, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
+    mfma_attn_kernel<NW, 1><<<grid, NW * 64, 32768, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
   return 0;
 }
 
