@@ -79,7 +79,7 @@ typedef struct vx_config {
   int32_t max_audio;       /* capacity: audio rows = [BOS] + prompt frames + generated frames */
   int32_t device;          /* HIP device ordinal */
   int32_t flags;           /* enum vx_flags */
-  int32_t max_batch;       /* slots for batched AR decode (vx_batch_*): 0/1 = batch-1 only, <= 32; bf16 only */
+  int32_t max_batch;       /* slots for batched AR decode (vx_batch_*): 0/1 = batch-1 only, <= 64; bf16 only */
 } vx_config;
 
 /* Sampling / stop-rule parameters of one AR decode (VALLE.inference args top_k, temperature,

@@ -7,6 +7,8 @@ import torch
 
 from conftest import Golden
 
+BMAX = 64  # slots per engine (vall-e_amd/engine.py)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -46,8 +48,8 @@ def test_batch_teacher_forced_against_fp32_oracle():
         eng.batch_prefill(b, x[0], y[0, :, 0].contiguous())
     eng.batch_decode(3, top_k=1, forced=[r[0].cuda() for r in refs])
     stride = eng.max_audio + 2
-    arg = eng.read("batch_argmax", (32, stride), dtype=torch.int32)
-    lg = eng.read("batch_logits", (32, 1088))
+    arg = eng.read("batch_argmax", (BMAX, stride), dtype=torch.int32)
+    lg = eng.read("batch_logits", (BMAX, 1088))
     for b, (toks, ref_logits) in enumerate(refs):
         got_toks, reason = eng.batch_result(b)
         assert torch.equal(got_toks, toks) and reason == 4  # forced tokens appended, closed by the forcing limit
@@ -78,7 +80,7 @@ def test_batch_last_logits_within_bf16_tolerance():
         want.append((toks, tr2["ar_logits"][K]))  # logits after K forced tokens
         eng.batch_prefill(b, x[0], y[0, :, 0].contiguous())
     eng.batch_decode(2, top_k=1, forced=[w[0].cuda() for w in want])
-    lg = eng.read("batch_logits", (32, 1088))
+    lg = eng.read("batch_logits", (BMAX, 1088))
     for b, (toks, ref) in enumerate(want):
         err = float((lg[b, :1025] - ref).abs().max())
         assert err <= 0.03 * float(ref.abs().max()), (b, err)
@@ -111,15 +113,15 @@ def test_batch_matches_batch1_engine_under_teacher_forcing():
     eng.batch_prefill(0, x[0], y[0, :, 0].contiguous())
     eng.batch_prefill(1, x2[0], y2[0, :, 0].contiguous())
     eng.batch_decode(2, top_k=1, forced=[toks.cuda(), toks[:5].cuda()])
-    arg = eng.read("batch_argmax", (32, eng.max_audio + 2), dtype=torch.int32)
+    arg = eng.read("batch_argmax", (BMAX, eng.max_audio + 2), dtype=torch.int32)
     agree = (arg[0, :n_pass] == arg1).float().mean().item()
     assert agree >= 0.97, agree
 
 
-@pytest.mark.parametrize("B", [8, 32])
+@pytest.mark.parametrize("B", [8, 32, 64])
 def test_full_batch_cfg1_geometry(B):
     """d=1024 L=12, B slots with ragged S in [40, 54]: shapes, ranges, per-slot lengths."""
-    cfg, sd, m = _setup(max_batch=32, d=1024, nhead=16, L=12)
+    cfg, sd, m = _setup(max_batch=max(B, 32), d=1024, nhead=16, L=12)
     shapes = [(40 + (i * 5) % 15, 225 if i % 2 == 0 else 150) for i in range(B)]
     u = _utts(shapes)
     eng = m.engine()
@@ -192,14 +194,14 @@ def test_batched_prefill_matches_per_slot_prefill(bos):
 
     for b in range(4):
         eng.batch_prefill(b, texts[b], proms[b])
-    lg_ref = eng.read("batch_logits", (32, 1088))[:4, :1025].clone()
+    lg_ref = eng.read("batch_logits", (BMAX, 1088))[:4, :1025].clone()
     eng.batch_decode(4, top_k=1, forced=forced)
-    arg_ref = eng.read("batch_argmax", (32, eng.max_audio + 2), dtype=torch.int32)[:4, :24].clone()
+    arg_ref = eng.read("batch_argmax", (BMAX, eng.max_audio + 2), dtype=torch.int32)[:4, :24].clone()
 
     eng.batch_prefill_all(texts, proms)
-    lg = eng.read("batch_logits", (32, 1088))[:4, :1025].clone()
+    lg = eng.read("batch_logits", (BMAX, 1088))[:4, :1025].clone()
     eng.batch_decode(4, top_k=1, forced=forced)
-    arg = eng.read("batch_argmax", (32, eng.max_audio + 2), dtype=torch.int32)[:4, :24].clone()
+    arg = eng.read("batch_argmax", (BMAX, eng.max_audio + 2), dtype=torch.int32)[:4, :24].clone()
 
     for b in range(4):
         err = float((lg[b] - lg_ref[b]).abs().max())

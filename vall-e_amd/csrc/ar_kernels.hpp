@@ -543,7 +543,8 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
   sm = wave_argmax_dpp(sm);
 
   // stop rule + append (valle.py:1044-1057); every lane evaluates the same scalars
-  int tok = sm.i, reason = 0;
+sm.i = min(sm.i, V - 1);  // non-finite logits: keep the lookup inside the table
+    int tok = sm.i, reason = 0;
   bool append = false, go = false;
   if (forced != nullptr) {
     if (pass >= n_forced) reason = 4;
@@ -689,7 +690,9 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
 #pragma unroll
   for (int w = 1; w < 4; ++w) sm = better(sm, ValIdx{s_sv[w], s_si[w]});
 
-  // stop rule + append (valle.py:1044-1057); every thread evaluates the same scalars
+  // stop rule + append (valle.py:1044-1057); every thread evaluates the same scalars.  Non-finite logits leave the
+  // argmax sentinel in sm.i: clamp so that the embedding lookup below can never leave the table
+  sm.i = min(sm.i, V - 1);
   int tok = sm.i, reason = 0;
   bool append = false, go = false;
   if (forced != nullptr) {

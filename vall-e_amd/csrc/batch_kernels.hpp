@@ -10,7 +10,7 @@
 
 namespace vx {
 
-constexpr int BMAX = 32;  // slots per engine (two 16-row MFMA halves)
+constexpr int BMAX = 64;  // slots per engine (up to four 16-row MFMA halves)
 typedef __bf16 bf16x8b_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -38,9 +38,9 @@ struct BgemmArgs {
 // group), its 4 waves take 4 K slices of NS steps and are summed through LDS in wave order.  Lane
 // (c = l&15, g = l>>4) holds act[b = c (+16)][8g..8g+8) and W[n0 + c][8g..8g+8) of each 32-wide step; the
 // accumulator has n on the lane and b = 4g + v in its 4 registers.
-template <int EPI, int NS>
+template <int EPI, int NS, int NH>  // NH 16-row halves of slots: 2 (B <= 32) or 4 (B <= 64)
 __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
-  __shared__ float red[4][8][64];
+  __shared__ float red[4][4 * NH][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int ntile = blockIdx.x / a.kgroups, kg = blockIdx.x - ntile * a.kgroups;
@@ -48,30 +48,31 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
   const int K = a.K;
   const int kbeg = kg * (K / a.kgroups) + wave * NS * 32;
   const bf16* wp = a.W + (size_t)min(n0 + c, a.N - 1) * K + kbeg + 8 * g;
-  const bf16* ap0 = a.A + (size_t)c * K + kbeg + 8 * g;
-  const bf16* ap1 = ap0 + (size_t)16 * K;
-  bf16x8b_t wf[NS], a0[NS], a1[NS];
+  const bf16* ap = a.A + (size_t)c * K + kbeg + 8 * g;
+  bf16x8b_t wf[NS], af[NH][NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) wf[s] = *reinterpret_cast<const bf16x8b_t*>(wp + s * 32);
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    a0[s] = *reinterpret_cast<const bf16x8b_t*>(ap0 + s * 32);
-    a1[s] = *reinterpret_cast<const bf16x8b_t*>(ap1 + s * 32);
-  }
-  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < NS; ++s)
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[s], wf[s], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s], wf[s], acc1, 0, 0, 0);
-  }
+    for (int h = 0; h < NH; ++h) af[h][s] = *reinterpret_cast<const bf16x8b_t*>(ap + (size_t)16 * h * K + s * 32);
+  f32x4_t acc[NH];
 #pragma unroll
-  for (int v = 0; v < 4; ++v) { red[wave][v][lane] = acc0[v]; red[wave][4 + v][lane] = acc1[v]; }
+  for (int h = 0; h < NH; ++h) acc[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[h][s], wf[s], acc[h], 0, 0, 0);
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) red[wave][4 * h + v][lane] = acc[h][v];
   __syncthreads();
-  // wave w finishes values {2w, 2w+1} of the 8 per lane: value i -> batch row b = 16*(i>>2) + 4g + (i&3)
+  // wave w finishes values {NH w, .., NH w + NH-1} of the 4 NH per lane: value i -> batch row b = 16*(i>>2) + 4g + (i&3)
   const int n = n0 + c;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int i = wave * 2 + u;
+  for (int u = 0; u < NH; ++u) {
+    const int i = wave * NH + u;
     const float x = ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
     const int b = 16 * (i >> 2) + 4 * g + (i & 3);
     if (b >= a.B || n >= a.N) continue;

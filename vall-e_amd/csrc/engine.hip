@@ -295,6 +295,9 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   VXC(dalloc(e, &e->Hn, n * dmax * e->esz));
   VXC(dalloc(e, &e->QKV, n * 3 * dmax * e->esz));
   VXC(dalloc(e, &e->ATT, n * dmax * e->esz));
+  // rows between the segments of a concatenated batch are never written by attention but are read by the
+  // out-projection: they must hold finite values (a NaN row would reach valid rows as 0 x NaN through its V^T column)
+  HIPC(hipMemset(e->ATT, 0, n * dmax * e->esz));
   e->vt_ld = ((e->n_max + 63) / 64) * 64 + 64;  // key-padded row length of V^T (16-byte aligned tiles)
   VXC(dalloc(e, &e->VT, (size_t)dmax * e->vt_ld * 2));
   HIPC(hipMemset(e->VT, 0, (size_t)dmax * e->vt_ld * 2));  // padding keys must stay finite (they meet P = 0)
@@ -1077,16 +1080,20 @@ extern "C" int vx_ar_result(vx_engine* e, int64_t* tokens, int32_t capacity, int
 }
 
 // ------------------------------------------------------------------------------ batched AR decode
+template <int EPI, int NH> static int launch_bgemm_h(const BgemmArgs& a, int ns, int grid, hipStream_t s) {
+  if (ns == 1) bgemm_kernel<EPI, 1, NH><<<grid, 256, 0, s>>>(a);
+  else if (ns == 2) bgemm_kernel<EPI, 2, NH><<<grid, 256, 0, s>>>(a);
+  else if (ns == 4) bgemm_kernel<EPI, 4, NH><<<grid, 256, 0, s>>>(a);
+  else if (ns == 8) bgemm_kernel<EPI, 8, NH><<<grid, 256, 0, s>>>(a);
+  else return fail(VX_ERR_UNSUPPORTED, "bgemm: %d steps per wave", ns);
+  return VX_OK;
+}
 template <int EPI> static int launch_bgemm(const BgemmArgs& a, hipStream_t s) {
   const int ns = a.K / (a.kgroups * 128);
   const int grid = ((a.N + 15) / 16) * a.kgroups;
   if (ns * a.kgroups * 128 != a.K) return fail(VX_ERR_UNSUPPORTED, "bgemm: K=%d kgroups=%d", a.K, a.kgroups);
-  if (ns == 1) bgemm_kernel<EPI, 1><<<grid, 256, 0, s>>>(a);
-  else if (ns == 2) bgemm_kernel<EPI, 2><<<grid, 256, 0, s>>>(a);
-  else if (ns == 4) bgemm_kernel<EPI, 4><<<grid, 256, 0, s>>>(a);
-  else if (ns == 8) bgemm_kernel<EPI, 8><<<grid, 256, 0, s>>>(a);
-  else return fail(VX_ERR_UNSUPPORTED, "bgemm: %d steps per wave", ns);
-  return VX_OK;
+  // two 16-slot MFMA halves up to 32 slots, four up to 64
+  return a.B <= 32 ? launch_bgemm_h<EPI, 2>(a, ns, grid, s) : launch_bgemm_h<EPI, 4>(a, ns, grid, s);
 }
 static int kgroups_for(int K) { return (K / 128) >= 4 ? 4 : 1; }
 static void launch_ln_batch(float* x, const float* part, int kgroups, const float* pbias, const float* gamma, const float* beta,

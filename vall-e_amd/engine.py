@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvallex.so")
 
 VX_PREC_F32, VX_PREC_BF16 = 0, 1
+BMAX = 64  # slots per engine (csrc/batch_kernels.hpp)
 VX_FLAG_TRACE_LOGITS, VX_FLAG_NO_GRAPH, VX_FLAG_SIMPLE_ROWS, VX_FLAG_POST_NORM, VX_FLAG_PRENET = 1, 2, 4, 8, 16
 STOP_REASONS = {0: "none", 1: "eos_argmax", 2: "eos_sample", 3: "length", 4: "max_new"}
 
