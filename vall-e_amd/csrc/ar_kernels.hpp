@@ -542,9 +542,9 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
   }
   sm = wave_argmax_dpp(sm);
 
+  sm.i = min(sm.i, V - 1);  // non-finite logits leave the argmax sentinel: keep the embedding lookup inside the table
   // stop rule + append (valle.py:1044-1057); every lane evaluates the same scalars
-sm.i = min(sm.i, V - 1);  // non-finite logits: keep the lookup inside the table
-    int tok = sm.i, reason = 0;
+  int tok = sm.i, reason = 0;
   bool append = false, go = false;
   if (forced != nullptr) {
     if (pass >= n_forced) reason = 4;
