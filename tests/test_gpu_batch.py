@@ -213,3 +213,31 @@ def test_batched_prefill_matches_per_slot_prefill(bos):
     for x, y, u in zip(a, b2, utts):
         assert x.shape == y.shape == (1, 16 * u[0].shape[1] + 1 - int(bos), 8)
         assert int(x.min()) >= 0 and int(x.max()) < 1024
+
+
+def test_outputs_do_not_depend_on_uninitialised_memory():
+    """VX_POISON=1 fills every fresh device allocation with 0xFF bytes (NaN / -1) before the engine initialises it.  The
+    same inputs must give the same codes with and without it, on the batch-1 path and on the batched path (padding rows
+    between the segments of a concatenated batch were once read before anything wrote them)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, json, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from test_gpu_batch import _setup, _utts\n"
+        "cfg, sd, m = _setup(max_batch=4)\n"
+        "u = _utts([(6, 30), (9, 12), (4, 55)])\n"
+        "a = m.inference_batch(u, top_k=5, seeds=[11, 22, 33])\n"
+        "torch.manual_seed(3); b = m.inference(u[1][0].cuda(), u[1][1].cuda(), u[1][2].cuda(), None, top_k=5)\n"
+        "print(json.dumps([t.flatten().tolist() for t in a] + [b.flatten().tolist()]))\n" % (root, os.path.join(root, "tests")))
+    outs = []
+    for poison in ("0", "1"):
+        env = dict(os.environ, VX_POISON=poison)
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
+    assert all(0 <= v < 1024 for seq in outs[1] for v in seq)

@@ -133,8 +133,16 @@ struct vx_engine {
   std::vector<void*> allocs;
 };
 
+// VX_POISON=1 (tests): every fresh device allocation is filled with 0xFF bytes (NaN as bf16 / fp32, -1 as integers)
+// before the engine's own initialisation runs, so a read of memory nothing wrote shows up as NaN output instead of
+// depending on what the allocator happened to hand back.
+static bool poison_on() {
+  static const bool on = [] { const char* v = getenv("VX_POISON"); return v && atoi(v) != 0; }();
+  return on;
+}
 static int dalloc(vx_engine* e, void** p, size_t bytes) {
   HIPC(hipMalloc(p, bytes ? bytes : 16));
+  if (poison_on()) HIPC(hipMemset(*p, 0xFF, bytes ? bytes : 16));
   e->allocs.push_back(*p);
   return VX_OK;
 }
@@ -1366,6 +1374,7 @@ static int ensure_rows(vx_engine* e, size_t rows, size_t audio_rows, size_t text
   auto regrow = [&](void** p, size_t bytes) -> int {
     for (auto& q : e->allocs) if (q == *p) { (void)hipFree(q); q = nullptr; }
     HIPC(hipMalloc(p, bytes));
+    if (poison_on()) HIPC(hipMemset(*p, 0xFF, bytes));
     e->allocs.push_back(*p);
     return VX_OK;
   };
