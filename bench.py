@@ -188,7 +188,7 @@ def main():
             "config": {"workload": (f"BASELINE configs[1]: d=1024 nhead=16 L=12, batch=1 AR top-k(10) + 7 NAR stages, "
                                     f"S={S_TEXT} P={P_PROMPT} -> T={T} frames x 8 codebooks, one utterance per GPU per step")
                        if Bt == 1 else
-                       (f"BASELINE configs[2]: d=1024 nhead=16 L=12, batch={Bt} concurrent utterances per GPU (padded KV, "
+                       (f"BASELINE configs[2]{'' if Bt == 32 else ' geometry at another batch size'}: d=1024 nhead=16 L=12, batch={Bt} concurrent utterances per GPU (padded KV, "
                         f"hipGraph step, one batched prefill and one batched NAR pass), S={S_TEXT} P={P_PROMPT} -> T={T} x 8"),
                        "parallelism": f"replica x{world} (utterance sharding, RCCL scatter/gather)"},
             "ar_tokens_per_s": round(tm["launches"] / (tm["decode_ms"] * 1e-3), 1),
