@@ -200,6 +200,9 @@ int vx_debug_stage_chain(int32_t nwg, int32_t stages, int32_t rows, int32_t mode
 /* Probe: L2 -> CU fill rate.  `grid` workgroups of `threads` lanes stream one shared region of `region_bytes` with `unroll`
  * independent 16-byte loads in flight per lane.  out[0] GB/s chip-wide, out[1] bytes/clock per busy CU, out[2] clock (GHz). */
 int vx_debug_l2_fill(int32_t grid, int32_t threads, int32_t unroll, int64_t region_bytes, int32_t iters, double* out);
+/* Probe builds only (csrc/build.py --stamps -> libvallex_stamps.so): phase timestamps (10 ns ticks) that workgroup 0 of the
+ * last stamped kernel recorded at its VX_STAMP points.  The product library returns VX_ERR_UNSUPPORTED. */
+int vx_debug_read_stamps(unsigned long long* out, int32_t n);
 
 #ifdef __cplusplus
 }

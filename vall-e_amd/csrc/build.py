@@ -37,6 +37,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return OUT
 
 
+def build_stamps() -> str:
+    """Probe build with in-kernel phase stamps (common.hpp VX_STAMP) -> libvallex_stamps.so; never loaded by the package."""
+    out = os.path.join(HERE, "libvallex_stamps.so")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-DVX_STAMPS",
+           "-Wno-unused-function", "-Wno-unused-variable", "-o", out] + [os.path.join(HERE, s) for s in SRCS]
+    subprocess.check_call(cmd, cwd=HERE)
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    if "--stamps" in sys.argv:
+        print(build_stamps())
+    else:
+        build(force="--force" in sys.argv)
+        print(OUT)

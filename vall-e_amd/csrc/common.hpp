@@ -4,6 +4,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// In-kernel phase stamps (probe builds only: `build.py --stamps` compiles libvallex_stamps.so with -DVX_STAMPS).  Lane 0 of
+// workgroup (0,0,0) records wall_clock64() (10 ns ticks) at VX_STAMP(i); read back with vx_debug_read_stamps.
+#ifdef VX_STAMPS
+extern __device__ unsigned long long g_vx_stamps[32];
+#define VX_STAMP(i)                                                                                        \
+  do {                                                                                                     \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_vx_stamps[i] = wall_clock64(); \
+  } while (0)
+#else
+#define VX_STAMP(i) do { } while (0)
+#endif
+
 namespace vx {
 
 constexpr int WAVE = 64;

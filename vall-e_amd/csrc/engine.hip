@@ -13,6 +13,9 @@
 #include <vector>
 
 #include "../../include/vallex.h"
+#ifdef VX_STAMPS
+__device__ unsigned long long g_vx_stamps[32];
+#endif
 #include "ar_kernels.hpp"
 #include "rows_kernels.hpp"
 #include "mfma_kernels.hpp"
@@ -1830,4 +1833,18 @@ extern "C" int vx_debug_l2_fill(int32_t grid, int32_t threads, int32_t unroll, i
   (void)hipFree(buf); (void)hipFree(sink);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
   return VX_OK;
+}
+
+
+// Phase stamps of the last stamped kernel launch (probe builds, common.hpp VX_STAMP): out[i] = 10 ns ticks.
+extern "C" int vx_debug_read_stamps(unsigned long long* out, int32_t n) {
+#ifdef VX_STAMPS
+  if (!out || n < 1 || n > 32) return fail(VX_ERR_ARG, "bad argument");
+  HIPC(hipDeviceSynchronize());
+  HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vx_stamps), (size_t)n * 8));
+  return VX_OK;
+#else
+  (void)out; (void)n;
+  return fail(VX_ERR_UNSUPPORTED, "library built without -DVX_STAMPS (python vall-e_amd/csrc/build.py --stamps)");
+#endif
 }

@@ -118,19 +118,24 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
     if (t + 1 < nk) lstore(NEXT, (t + 1) & 1);
     __syncthreads();
   };
+  VX_STAMP(0);
   gload(I0{}, 0);
   gload(I1{}, min(BK, K - BK));
   gload(I2{}, min(2 * BK, K - BK));
+  VX_STAMP(1);
   lstore(I0{}, 0);
   __syncthreads();
+  VX_STAMP(2);
   int kt = 0;
   for (; kt + 3 <= nk; kt += 3) {
     step(I0{}, I1{}, kt);
     step(I1{}, I2{}, kt + 1);
     step(I2{}, I0{}, kt + 2);
+    if (kt == 0) VX_STAMP(3);  // after the first three K tiles
   }
   if (kt < nk) step(I0{}, I1{}, kt);
   if (kt + 1 < nk) step(I1{}, I2{}, kt + 1);
+  VX_STAMP(4);
 
   // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
   if constexpr (!OUT_F32) {
@@ -192,6 +197,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
       }
     }
   }
+  VX_STAMP(5);
 }
 
 // ---- wave-tile GEMM: every wave owns one 64x64 output tile and stages its own A / W tiles through a

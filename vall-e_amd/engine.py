@@ -72,6 +72,7 @@ _SIGS = {
     "vx_debug_launch_floor": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "vx_debug_stage_chain": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_double)]),
     "vx_debug_l2_fill": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
+    "vx_debug_read_stamps": (C.c_int, [C.POINTER(C.c_uint64), C.c_int32]),
 }
 
 
