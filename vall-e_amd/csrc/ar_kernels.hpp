@@ -43,11 +43,16 @@ struct GemvArgs {
   void* vcache;
   int d, hd, ctx_max, nhead;
   const ArState* st;
+  // NPF > 0: L2 warm-up for the NEXT kernel of the decode step.  Workgroup b touches bytes [b pf_slice, (b+1) pf_slice) of
+  // `pf` - the slice workgroup b of the next GEMV streams - so that kernel finds its weights in the L2 of the XCD
+  // it runs on (workgroups are placed round-robin over the 8 XCDs in both launches).  Speed only: the values are never used.
+  const void* pf;
+  unsigned pf_slice, pf_total;
 };
 
 // y = W x (+epilogue).  One wave owns RPW rows at a time; a row is KCH 16-byte loads per lane;
 // lane l holds x[(c*64 + l)*VEC .. +VEC) for chunk c.
-template <typename WT, int KCH, int RPW, int PRO>
+template <typename WT, int KCH, int RPW, int PRO, int NPF = 0>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   constexpr int VEC = Vec16<WT>::N;
   constexpr int V4 = VEC / 4;
@@ -118,6 +123,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     }
   };
   issue(g);
+  // next kernel's weights, behind this kernel's own stream (vmcnt retires in order: the waits below do not cover them)
+  uint4 pfv[NPF > 0 ? NPF : 1];
+  if (NPF > 0) {
+    const unsigned lim = min(a.pf_slice, a.pf_total - min(a.pf_total, blockIdx.x * a.pf_slice));  // bytes of this slice inside pf
+    const char* pb = reinterpret_cast<const char*>(a.pf) + min((size_t)blockIdx.x * a.pf_slice, (size_t)a.pf_total - 16);
+#pragma unroll
+    for (int i = 0; i < NPF; ++i)
+      pfv[i] = *reinterpret_cast<const uint4*>(pb + min((unsigned)(i * 4096 + tid * 16), max(lim, 16u) - 16u));
+  }
   // pin the weight loads HERE: without this the scheduler sinks them below the prologue, next to
   // their first use, and the HBM round trip is serialised behind the LayerNorm
   __builtin_amdgcn_sched_barrier(0);
@@ -202,7 +216,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   }
 
   // ---- (D) dot products, wave reduction, epilogue -------------------------------------------
-  for (;;) {
+  // The first row group runs outside the loop: merged into it, the wait in front of the dot products is the loop's
+  // (`vmcnt(7..0)`, sized for a later pass) and covers the warm-up loads as well.
+  auto rows = [&]() {
     float acc[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
@@ -247,6 +263,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         default: a.y[row] = v; break;
       }
     }
+  };
+  rows();
+  for (;;) {
     g += nwaves;
     if (g * RPW >= N) break;
     {
@@ -255,6 +274,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       if (has_res) e_res = (a.res ? a.res : a.y)[rc];
     }
     issue(g);
+    rows();
+  }
+  if (NPF > 0) {  // the warm-up loads stay live (and unwaited) until here
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) asm volatile("" ::"v"(pfv[i].x), "v"(pfv[i].y), "v"(pfv[i].z), "v"(pfv[i].w));
   }
 }
 

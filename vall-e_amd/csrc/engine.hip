@@ -513,23 +513,37 @@ extern "C" int vx_finalize_weights(vx_engine* e) {
 // ------------------------------------------------------------------------------ launch helpers
 template <typename WT, int KCH, int RPW, int PRO>
 static void launch_gemv_inst(const GemvArgs& a, int grid, hipStream_t s) {
-  gemv_kernel<WT, KCH, RPW, PRO><<<grid, 256, 0, s>>>(a);
+  if (a.pf != nullptr) gemv_kernel<WT, KCH, RPW, PRO, 8><<<grid, 256, 0, s>>>(a);
+  else gemv_kernel<WT, KCH, RPW, PRO, 0><<<grid, 256, 0, s>>>(a);
 }
 
-// Chooses the instance: KCH = 16-byte chunks per lane per row, RPW = rows per wave so that one
+// The instance for (N, K): KCH = 16-byte chunks per lane per row, RPW = rows per wave so that one
 // wave-iteration covers N over 4*grid waves, with at most 16 weight registers-quads in flight.
+struct GemvPlan { int grid, kch, rpw; };
+static GemvPlan gemv_plan(int N, int K, int vec, int num_cu) {
+  const int need_kch = (K + 64 * vec - 1) / (64 * vec);
+  GemvPlan p{num_cu, 1, 1};
+  while (p.kch < need_kch) p.kch <<= 1;
+  if ((N + 3) / 4 < p.grid) p.grid = (N + 3) / 4;
+  const int need_rpw = (N + p.grid * 4 - 1) / (p.grid * 4);
+  p.rpw = need_rpw >= 3 ? 4 : need_rpw;
+  while (p.rpw * p.kch > 16 && p.rpw > 1) p.rpw >>= 1;
+  return p;
+}
+// Points `a` at the weights the NEXT GEMV of the decode step streams (GemvArgs.pf): 32 KB per workgroup at most.
+static void gemv_prefetch(GemvArgs& a, const void* Wn, int Nn, int Kn, bool bf, int num_cu) {
+  const GemvPlan p = gemv_plan(Nn, Kn, bf ? 8 : 4, num_cu);
+  const size_t slice = (size_t)4 * p.rpw * Kn * (bf ? 2 : 4), total = (size_t)Nn * Kn * (bf ? 2 : 4);
+  if (Wn == nullptr || slice > 32768 || total >= (1ull << 32) || total < 16) return;
+  a.pf = Wn; a.pf_slice = (unsigned)slice; a.pf_total = (unsigned)total;
+}
+
 template <typename WT, int PRO> static int launch_gemv_p(const GemvArgs& a, int num_cu, hipStream_t s) {
   constexpr int VEC = Vec16<WT>::N;
   if (a.K % VEC || a.K > 4096 || a.K % 4) return fail(VX_ERR_UNSUPPORTED, "gemv: K=%d unsupported", a.K);
-  const int need_kch = (a.K + 64 * VEC - 1) / (64 * VEC);
-  int kch = 1;
-  while (kch < need_kch) kch <<= 1;
+  const GemvPlan pl = gemv_plan(a.N, a.K, VEC, num_cu);
+  const int kch = pl.kch, rpw = pl.rpw, grid = pl.grid;
   if (kch > 16 || (PRO != PRO_COPY && (kch > 4 || a.K > 1024))) return fail(VX_ERR_UNSUPPORTED, "gemv: K=%d too large for prologue %d", a.K, PRO);
-  int grid = num_cu;
-  if ((a.N + 3) / 4 < grid) grid = (a.N + 3) / 4;
-  const int need_rpw = (a.N + grid * 4 - 1) / (grid * 4);
-  int rpw = need_rpw >= 3 ? 4 : need_rpw;
-  while (rpw * kch > 16 && rpw > 1) rpw >>= 1;
 #define GV(KC, RP) if (kch == KC && rpw == RP) { launch_gemv_inst<WT, KC, RP, PRO>(a, grid, s); return VX_OK; }
   GV(1, 1) GV(1, 2) GV(1, 4) GV(2, 1) GV(2, 2) GV(2, 4) GV(4, 1) GV(4, 2) GV(4, 4)
   if constexpr (PRO == PRO_COPY) { GV(8, 1) GV(8, 2) GV(16, 1) }
@@ -930,6 +944,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
   }
   const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd * e->esz;
   const float scale = 1.0f / sqrtf((float)hd);
+  static const bool pf_on = !(getenv("VX_AR_PREFETCH") && atoi(getenv("VX_AR_PREFETCH")) == 0);
   for (int li = 0; li < c.num_layers; ++li) {
     const LayerW& l = e->ar_l[li];
     char* kc = (char*)e->kv + (size_t)li * kv_layer;
@@ -947,6 +962,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
       if (li == 0) { a.pro = PRO_COPY; }
       else { a.gamma = e->ar_l[li - 1].n2_g; a.beta = e->ar_l[li - 1].n2_b; a.xnorm_out = e->ar_xn; res = e->ar_xn; }
     }
+    if (pf_on) gemv_prefetch(a, l.out_w, d, d, e->bf16, e->num_cu);  // used two kernels later; the attention kernel reads no weights
     VXC(launch_gemv(e->bf16, a, e->num_cu, s));
     if (e->bf16) attn_decode_kernel<bf16, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale);
     else attn_decode_kernel<float, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale);
@@ -955,6 +971,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     o.st = e->d_st; o.hd = hd; o.nhead = H;
     o.W = l.out_w; o.bias = l.out_b; o.part = e->ar_part; o.y = e->ar_x; o.N = d; o.K = d; o.pro = PRO_ATTN; o.epi = EPI_RESID;
     o.res = res;
+    if (pf_on) gemv_prefetch(o, l.w1, 4 * d, d, e->bf16, e->num_cu);
     VXC(launch_gemv(e->bf16, o, e->num_cu, s));
     // f = relu(linear1(LN2(x)))
     GemvArgs f{};
@@ -962,12 +979,17 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     f.W = l.w1; f.bias = l.b1; f.x = e->ar_x; f.gamma = l.n2_g; f.beta = l.n2_b; f.y = e->ar_f;
     f.N = 4 * d; f.K = d; f.pro = PRO_LN; f.epi = EPI_RELU;
     if (post) { f.gamma = l.n1_g; f.beta = l.n1_b; f.xnorm_out = e->ar_xn; }  // x = norm1(x + sa(x)), kept in ar_xn
+    if (pf_on) gemv_prefetch(f, l.w2, d, 4 * d, e->bf16, e->num_cu);
     VXC(launch_gemv(e->bf16, f, e->num_cu, s));
     // x += linear2(f)
     GemvArgs g{};
     g.st = e->d_st;
     g.W = l.w2; g.bias = l.b2; g.x = e->ar_f; g.y = e->ar_x; g.N = d; g.K = 4 * d; g.pro = PRO_COPY; g.epi = EPI_RESID;
     if (post) g.res = e->ar_xn;  // raw sum norm1(..) + ff(..); its norm2 runs in the next layer's (or the head's) prologue
+    if (pf_on) {
+      if (li + 1 < c.num_layers) gemv_prefetch(g, e->ar_l[li + 1].in_w, 3 * d, d, e->bf16, e->num_cu);
+      else gemv_prefetch(g, W<void>(e, "ar_predict_layer.weight"), AR_VOCAB, d, e->bf16, e->num_cu);
+    }
     VXC(launch_gemv(e->bf16, g, e->num_cu, s));
   }
   VXC(enqueue_head(e, s));
