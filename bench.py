@@ -38,7 +38,8 @@ def measured_traffic(ctx_mean: float):
     """HBM bytes per AR step from the committed PMC profile (profiles/r01_pmc_ar_step.json: FETCH_SIZE x2 as the
     microarch guide prescribes for gfx950, split into the ctx-independent GEMV part and the per-cached-row
     attention part so that it can be quoted at this run's mean context).  None if the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_ar_step.json")
+    off = os.environ.get("VX_AR_PREFETCH", "1") == "0"  # the engine's weight warm-up doubles the fabric requests (see the profile's "reading")
+    path = os.path.join(ROOT, "profiles", "r01_pmc_ar_step_prefetch_off.json" if off else "r01_pmc_ar_step.json")
     if not os.path.isfile(path):
         return None
     p = json.load(open(path))
@@ -202,6 +203,9 @@ def main():
                          "traffic": measured_traffic(ctx_mean) if (args.precision == "bf16" and Bt == 1) else None,
                          "bytes_per_launch": int(step_bytes)},
         }
+        if Bt == 1 and os.environ.get("VX_AR_PREFETCH", "1") != "0":
+            out["roofline"]["traffic_note"] = ("fabric read requests (FETCH_SIZE x2), ~2x algorithmic by design: each GEMV also requests the next "
+                                               "GEMV's weights so that they are served from the Infinity Cache; VX_AR_PREFETCH=0: 1.05x, -6% tokens/s")
         if world == 1 and not args.no_cpu_baseline:
             x, x_lens, y = utts[0]
             out["cpu_baseline"] = cpu_baseline(sd, cfg, x, x_lens, y, args.cpu_tokens)
