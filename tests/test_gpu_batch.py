@@ -22,7 +22,7 @@ def _setup(max_batch=4, d=256, nhead=4, L=4, **kw):
 
     cfg = ModelConfig(decoder_dim=d, nhead=nhead, num_decoder_layers=L, prefix_mode=1)
     sd = synthetic_state_dict(cfg, 0)
-    m = VALLE(d, nhead, L, prefix_mode=1, precision="bf16", max_text=64, max_audio=700, print_eos=False, max_batch=max_batch, **kw)
+    m = VALLE(d, nhead, L, prefix_mode=1, precision=kw.pop("precision", "bf16"), max_text=64, max_audio=700, print_eos=False, max_batch=max_batch, **kw)
     m.load_state_dict(sd)
     return cfg, sd, m.to("cuda:0").eval()
 
@@ -241,3 +241,30 @@ def test_outputs_do_not_depend_on_uninitialised_memory():
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1]
     assert all(0 <= v < 1024 for seq in outs[1] for v in seq)
+
+
+def test_weight_warm_up_does_not_change_results():
+    """The AR step's L2 / Infinity-Cache warm-up (GemvArgs.pf: every GEMV also issues unused loads over the next GEMV's
+    weights) is speed only: VX_AR_PREFETCH=0 and the default must give identical codes, in fp32 and in bf16."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, json, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from test_gpu_batch import _setup, _utts\n"
+        "out = []\n"
+        "for prec in ('fp32', 'bf16'):\n"
+        "    cfg, sd, m = _setup(max_batch=0, precision=prec)\n"
+        "    u = _utts([(9, 12)])[0]\n"
+        "    torch.manual_seed(3); out.append(m.inference(u[0].cuda(), u[1].cuda(), u[2].cuda(), None, top_k=5).flatten().tolist())\n"
+        "print(json.dumps(out))\n" % (root, os.path.join(root, "tests")))
+    outs = []
+    for pf in ("0", "1"):
+        env = dict(os.environ, VX_AR_PREFETCH=pf)
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
