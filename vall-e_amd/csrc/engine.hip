@@ -526,7 +526,7 @@ static GemvPlan gemv_plan(int N, int K, int vec, int num_cu) {
   while (p.kch < need_kch) p.kch <<= 1;
   if ((N + 3) / 4 < p.grid) p.grid = (N + 3) / 4;
   const int need_rpw = (N + p.grid * 4 - 1) / (p.grid * 4);
-  p.rpw = need_rpw >= 3 ? 4 : need_rpw;
+  p.rpw = need_rpw > 3 ? 4 : need_rpw;  // 3 rows per wave for N = 3 x 4 x grid (the QKV projection): every wave busy
   while (p.rpw * p.kch > 16 && p.rpw > 1) p.rpw >>= 1;
   return p;
 }
@@ -545,7 +545,7 @@ template <typename WT, int PRO> static int launch_gemv_p(const GemvArgs& a, int 
   const int kch = pl.kch, rpw = pl.rpw, grid = pl.grid;
   if (kch > 16 || (PRO != PRO_COPY && (kch > 4 || a.K > 1024))) return fail(VX_ERR_UNSUPPORTED, "gemv: K=%d too large for prologue %d", a.K, PRO);
 #define GV(KC, RP) if (kch == KC && rpw == RP) { launch_gemv_inst<WT, KC, RP, PRO>(a, grid, s); return VX_OK; }
-  GV(1, 1) GV(1, 2) GV(1, 4) GV(2, 1) GV(2, 2) GV(2, 4) GV(4, 1) GV(4, 2) GV(4, 4)
+  GV(1, 1) GV(1, 2) GV(1, 3) GV(1, 4) GV(2, 1) GV(2, 2) GV(2, 3) GV(2, 4) GV(4, 1) GV(4, 2) GV(4, 3) GV(4, 4)
   if constexpr (PRO == PRO_COPY) { GV(8, 1) GV(8, 2) GV(16, 1) }
 #undef GV
   return fail(VX_ERR_UNSUPPORTED, "gemv: no instance for kch=%d rpw=%d", kch, rpw);
