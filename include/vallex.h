@@ -65,8 +65,8 @@ enum vx_flags {
 /* Mirrors VALLE.__init__ (valle.py:727-760) / get_model (models/__init__.py:112-124). */
 typedef struct vx_config {
   int32_t struct_size;     /* = sizeof(vx_config) */
-  int32_t d_model;         /* --decoder-dim */
-  int32_t nhead;           /* --nhead */
+  int32_t d_model;         /* --decoder-dim: multiple of 8, <= 1024 */
+  int32_t nhead;           /* --nhead: d_model / nhead in {4, 8, 16, 32, 64}; 64 is the tuned geometry, the others run on plain kernels (batch-1) */
   int32_t num_layers;      /* --num-decoder-layers */
   int32_t nar_d_model;     /* int(d_model * scale_factor), valle.py:83 */
   int32_t nar_nhead;       /* int(nhead * scale_factor),   valle.py:234 */

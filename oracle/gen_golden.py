@@ -58,6 +58,14 @@ CASES = {
     "tiny_prenet_postnorm_mode0": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=0, add_prenet=True, norm_first=False), 6, 11, 3, 1.0, 32, None, (0, 5)),
     "tiny_prenet_mode2_bos": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=2, add_prenet=True, prepend_bos=True, num_quantizers=7), 9, 12, 1, 1.0, None, 4, (0, 5)),
     # BASELINE.json configs[1]: d=1024 nhead=16 L=12, top-k 10, S=47 -> 753 tokens x 8 codebooks
+    # the geometry and option walk of the reference's own test (valle_test.py:90-135): decoder_dim 64 / nhead 16 (head_dim 4),
+    # 4 layers, post-norm + prenets, text (1,8), prompt (1,16,8), default sampling (top_k=-100); scale 0.5 from the second
+    # iteration on, prepend_bos toggling, one quantizer fewer each time
+    "reftest_mode0": (dict(decoder_dim=64, nhead=16, num_decoder_layers=4, prefix_mode=0, norm_first=False, add_prenet=True), 8, 16, -100, 1.0, 51, 2, (0, 5)),
+    "reftest_mode1_scale05_bos_q7": (dict(decoder_dim=64, nhead=16, num_decoder_layers=4, prefix_mode=1, norm_first=False, add_prenet=True,
+                                          scale_factor=0.5, prepend_bos=True, num_quantizers=7), 8, 16, -100, 1.0, 52, 2, (0, 5)),
+    "reftest_mode2_scale05_q6": (dict(decoder_dim=64, nhead=16, num_decoder_layers=4, prefix_mode=2, norm_first=False, add_prenet=True,
+                                      scale_factor=0.5, num_quantizers=6), 8, 16, -100, 1.0, 53, 2, (0, 5)),
     "cfg1_topk10": (dict(decoder_dim=1024, nhead=16, num_decoder_layers=12, prefix_mode=1), 47, 225, 10, 1.0, 1234, None, (0, 1, 376, 752)),
 }
 SMALL = [k for k in CASES if not k.startswith("cfg1")]

@@ -50,6 +50,28 @@ def test_error_reporting_without_gpu(lib):
     assert b"struct_size" in lib.vx_last_error()
 
 
+def test_geometry_checks_without_gpu(lib):
+    """Geometry is validated before any HIP call: head_dim 4..64 (powers of two) is accepted by the Python mirror, anything
+    else and batched decode at head_dim != 64 are refused loudly on both sides of the C ABI."""
+    import ctypes as C
+    from valle_amd.engine import VxConfig
+    from valle_amd.models import VALLE
+
+    VALLE(64, 16, 4, norm_first=False, add_prenet=True)  # the reference's own test geometry (valle_test.py:93-95)
+    with pytest.raises(NotImplementedError, match="head_dim"):
+        VALLE(96, 8, 2)  # head_dim 12
+    with pytest.raises(NotImplementedError, match="head_dim 64"):
+        VALLE(64, 16, 4, max_batch=4)
+    c = VxConfig()
+    c.struct_size = C.sizeof(VxConfig)
+    c.d_model, c.nhead, c.num_layers = 96, 8, 2
+    c.nar_d_model, c.nar_nhead, c.nar_num_layers = 96, 8, 2
+    c.num_quantizers, c.prefix_mode, c.precision, c.max_text, c.max_audio = 8, 1, 0, 16, 64
+    h = C.c_void_p()
+    assert lib.vx_create(C.byref(c), C.byref(h)) != 0
+    assert b"head_dim" in lib.vx_last_error()
+
+
 def test_wrapper_argument_checks_match_reference():
     from valle_amd.models import VALLE
 

@@ -104,7 +104,7 @@ def test_torch_cpu_sampling_mode_follows_global_generator():
 
 @pytest.mark.parametrize("name,simple", [("cfg0_topk10", False), ("cfg0_topk10", True), ("tiny_mode0", False),
                                          ("tiny_mode2_q6", False), ("cfg0_postnorm", False), ("cfg0_postnorm", True),
-                                         ("cfg1_topk10", False)])
+                                         ("cfg1_topk10", False), ("reftest_mode0", False), ("reftest_mode1_scale05_bos_q7", False)])
 def test_bf16_engine_teacher_forced(name, simple):
     from oracle import valle_oracle as vo
 
@@ -339,3 +339,50 @@ def test_random_option_walk_matches_oracle(seed):
                       exp_noise=None if noise is None else noise.cuda()).cpu()
     assert got.shape == want.shape, (kw, S, P, top_k, temp)
     assert torch.equal(got, want), (kw, S, P, top_k, temp)
+
+
+def test_valle_like_the_reference_test():
+    """The reference's own `test_valle` (valle/tests/valle_test.py:90-135), inference half: decoder_dim 64 / nhead 16 (head_dim 4),
+    4 layers, post-norm, prenets, numpy-random text (8) and prompt (16 x 8), prefix modes 0 / 1 / 2 with scale_factor 0.5 from
+    the second iteration on, prepend_bos toggling and one quantizer fewer each time, default sampling (top_k=-100).  The
+    reference only checks that it runs; here every iteration must also equal the oracle on the same weights and draws."""
+    import numpy as np
+
+    from oracle import valle_oracle as vo
+    from valle_amd.models import get_model
+    import __graft_entry__ as ge
+
+    ge.build()
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy(rs.randint(0, 100, size=[4, 8]))
+    x_lens = torch.from_numpy(rs.randint(4, 8, size=[4]))
+    x_lens[-1] = 8
+    enroll_x_lens = torch.from_numpy(rs.randint(1, 3, size=[4]))
+    y = torch.from_numpy(rs.randint(0, 1000, size=[4, 16, 8]))
+
+    params = dict(decoder_dim=64, nhead=16, num_decoder_layers=4, norm_first=False, add_prenet=True, model_name="VALL-E",
+                  share_embedding=True, scale_factor=1.0, prepend_bos=False, num_quantizers=8, precision="fp32", sampling="torch_cpu",
+                  max_text=32, max_audio=400)
+    for it, mode in enumerate([0, 1, 2]):
+        params["prefix_mode"] = mode
+        torch.manual_seed(100 + it)  # the constructor draws its random-init seed from the global generator, like nn.Module
+        model = get_model(params)
+        model.print_eos = False
+        model.to("cuda:0")
+        model.eval()
+        torch.manual_seed(7 + it)
+        codes = model.inference(x[-1:].cuda(), x_lens[-1:].cuda(), y[-1:].cuda(), enroll_x_lens=enroll_x_lens)
+        Q = params["num_quantizers"]
+        assert codes.ndim == 3 and codes.shape[0] == 1 and codes.shape[2] == Q and codes.shape[1] >= 1
+        assert int(codes.min()) >= 0 and int(codes.max()) < 1024
+
+        cfg = model.cfg
+        om = vo.OracleModel(model.state_dict(), 64, 16, 4, mode, cfg.prepend_bos, Q, cfg.scale_factor, False, True)
+        torch.manual_seed(7 + it)
+        noise = torch.stack([torch.empty(1, 1025).exponential_(1)[0] for _ in range(16 * 8 + 3)])
+        want = vo.inference_cached(om, x[-1:], x_lens[-1:], y[-1:], enroll_x_lens, -100, 1.0, noise)
+        assert torch.equal(codes.cpu(), want), (it, mode)
+
+        params["scale_factor"] = 0.5
+        params["prepend_bos"] = not params["prepend_bos"]
+        params["num_quantizers"] -= 1

@@ -378,6 +378,55 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   }
 }
 
+// ---- the same split-KV partials for head sizes other than 64 (4 .. 32: the reference's own tests run head_dim 4,
+// valle_test.py:93-95).  Plain per-thread online softmax over every 256th key of the split, merged through LDS;
+// nothing here is tuned - these geometries are test-sized.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_decode_small_kernel(const float* __restrict__ q, const T* __restrict__ kc,
+                                                                const T* __restrict__ vc, float* __restrict__ part,
+                                                                const ArState* __restrict__ st, int ctx_max, float scale) {
+  __shared__ float sm_m[256], sm_l[256];
+  __shared__ float sm_o[256][HD + 1];
+  const int h = blockIdx.x / ATT_NSPLIT, s = blockIdx.x - h * ATT_NSPLIT;
+  const int tid = threadIdx.x;
+  const int ctx = st->row + 1;
+  const int chunk = (ctx + ATT_NSPLIT - 1) / ATT_NSPLIT;
+  const int j0 = s * chunk, j1 = min(ctx, j0 + chunk);
+  float qv[HD], o[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) { qv[c] = q[h * HD + c]; o[c] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  for (int j = j0 + tid; j < j1; j += 256) {
+    const T* kr = kc + ((size_t)h * ctx_max + j) * HD;
+    const T* vr = vc + ((size_t)h * ctx_max + j) * HD;
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dot = fmaf(to_f32(kr[c]), qv[c], dot);
+    const float sc = dot * scale, mn = fmaxf(m, sc);
+    const float corr = (m == -INFINITY) ? 0.f : expf(m - mn), pj = expf(sc - mn);
+    l = l * corr + pj;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) o[c] = o[c] * corr + pj * to_f32(vr[c]);
+    m = mn;
+  }
+  sm_m[tid] = m;
+  __syncthreads();
+  float M = -INFINITY;
+  for (int i = 0; i < 256; ++i) M = fmaxf(M, sm_m[i]);
+  const float f = (m == -INFINITY) ? 0.f : expf(m - M);
+  sm_l[tid] = l * f;
+#pragma unroll
+  for (int c = 0; c < HD; ++c) sm_o[tid][c] = o[c] * f;
+  __syncthreads();
+  if (tid < HD) {
+    float so = 0.f, sl = 0.f;
+    for (int i = 0; i < 256; ++i) { so += sm_o[i][tid]; sl += sm_l[i]; }
+    float* p = part + (size_t)blockIdx.x * ATT_PSTRIDE;
+    if (tid == 0) { p[0] = M; p[1] = sl; }
+    p[4 + tid] = so;
+  }
+}
+
 // ---- sampling + stop rule + next-token embedding (valle.py:1040-1057, 1287-1302) -----------
 struct SampleArgs {
   const float* logits;   // base of the logits rows (V per pass when tracing, else one row)

@@ -69,6 +69,7 @@ constexpr int POLL_CHUNK = 32;
 struct vx_engine {
   vx_config cfg{};
   bool bf16 = false;
+  bool hd64 = true;  // head_dim 64 in both stacks: the MFMA row kernels and the batched decode apply
   size_t esz = 4;  // bytes per matrix / KV / GEMM-operand element
   int num_cu = 256;
   hipStream_t es = nullptr;
@@ -250,10 +251,18 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   if (c.num_quantizers < 1 || c.num_quantizers > 8) return fail(VX_ERR_ARG, "num_quantizers must be 1..8");
   if (c.prefix_mode != 0 && c.prefix_mode != 1 && c.prefix_mode != 2 && c.prefix_mode != 4)
     return fail(VX_ERR_ARG, "prefix_mode must be 0/1/2/4");
-  if (c.d_model / c.nhead != 64 || (c.num_quantizers > 1 && (c.nar_nhead <= 0 || c.nar_d_model / c.nar_nhead != 64)))
-    return fail(VX_ERR_UNSUPPORTED, "only head_dim 64 is built (d_model/nhead)");
-  if (c.d_model % 64 || c.d_model > 1024 || c.nar_d_model > 1024)
-    return fail(VX_ERR_UNSUPPORTED, "d_model must be a multiple of 64 and <= 1024");
+  // head_dim 64 is the built geometry (MFMA attention, batched decode); 4 / 8 / 16 / 32 run on the plain kernels, batch-1
+  // only: the reference's own tests use decoder_dim 64 / nhead 16 and half of that for the NAR stack (valle_test.py:93-95)
+  auto hd_ok = [](int hd) { return hd == 4 || hd == 8 || hd == 16 || hd == 32 || hd == 64; };
+  if (c.num_quantizers > 1 && (c.nar_nhead <= 0 || c.nar_d_model % c.nar_nhead)) return fail(VX_ERR_ARG, "bad nar_d_model/nar_nhead");
+  if (!hd_ok(c.d_model / c.nhead) || (c.num_quantizers > 1 && !hd_ok(c.nar_d_model / c.nar_nhead)))
+    return fail(VX_ERR_UNSUPPORTED, "head_dim (d_model/nhead) must be 4, 8, 16, 32 or 64");
+  const bool hd64 = c.d_model / c.nhead == 64 && (c.num_quantizers == 1 || c.nar_d_model / c.nar_nhead == 64);
+  if (c.d_model % 8 || c.d_model > 1024 || c.nar_d_model > 1024 || (c.num_quantizers > 1 && c.nar_d_model % 8))
+    return fail(VX_ERR_UNSUPPORTED, "d_model must be a multiple of 8 and <= 1024");
+  if (hd64 && (c.d_model % 64 || (c.num_quantizers > 1 && c.nar_d_model % 64)))
+    return fail(VX_ERR_UNSUPPORTED, "d_model must be a multiple of 64 at head_dim 64");
+  if (!hd64 && c.max_batch > 1) return fail(VX_ERR_UNSUPPORTED, "batched decode needs head_dim 64");
   if (c.max_text <= 0 || c.max_audio <= 0) return fail(VX_ERR_ARG, "capacities must be positive");
   if (c.precision != VX_PREC_F32 && c.precision != VX_PREC_BF16) return fail(VX_ERR_ARG, "bad precision");
   if ((c.flags & (VX_FLAG_POST_NORM | VX_FLAG_PRENET)) && c.max_batch > 1)
@@ -266,6 +275,7 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   vx_engine* e = new vx_engine();
   e->cfg = c;
   e->bf16 = c.precision == VX_PREC_BF16;
+  e->hd64 = hd64;
   e->esz = e->bf16 ? 2 : 4;
   hipDeviceProp_t prop;
   HIPC(hipGetDeviceProperties(&prop, c.device));
@@ -577,7 +587,7 @@ static int gemm_rows_t(bool mfma, const T* A, const T* Wt, const float* bias, vo
   return VX_OK;
 }
 
-static bool use_mfma(const vx_engine* e) { return e->bf16 && !(e->cfg.flags & VX_FLAG_SIMPLE_ROWS); }
+static bool use_mfma(const vx_engine* e) { return e->bf16 && e->hd64 && !(e->cfg.flags & VX_FLAG_SIMPLE_ROWS); }
 
 static int gemm_rows(vx_engine* e, const void* A, const void* Wt, const float* bias, void* C, int M, int N, int K,
                      int epi, bool out_f32, bool emit_vt = false) {
@@ -632,15 +642,22 @@ static int cast_rows(vx_engine* e, const float* x, void* out, size_t n) {
 }
 
 static int attn_rows(vx_engine* e, const void* qkv, void* out, int M, int d, int H, int text_len) {
-  const float scale = 1.0f / sqrtf(64.0f);
+  const int hd = d / H;
+  const float scale = 1.0f / sqrtf((float)hd);
   if (e->nseg > 0)  // batched NAR: one launch over all segments of the concatenated rows
     return mfma_attn_dispatch((const bf16*)qkv, (const bf16*)e->VT, e->vt_ld, (bf16*)out, M, d, H, text_len, e->es,
                               e->d_seg_start, e->d_seg_len, e->nseg, e->max_seg_len, e->seg_text_on ? e->d_seg_text : nullptr);
   if (use_mfma(e)) return mfma_attn_dispatch((const bf16*)qkv, (const bf16*)e->VT, e->vt_ld, (bf16*)out, M, d, H, text_len, e->es);
   dim3 grid((M + 63) / 64, H);
-  if (e->bf16) attn_rows_simple_kernel<bf16, 64><<<grid, 256, 0, e->es>>>((const bf16*)qkv, (bf16*)out, M, d, text_len, scale);
-  else attn_rows_simple_kernel<float, 64><<<grid, 256, 0, e->es>>>((const float*)qkv, (float*)out, M, d, text_len, scale);
-  return VX_OK;
+#define AR(HDV)                                                                                                                   \
+  if (hd == HDV) {                                                                                                                \
+    if (e->bf16) attn_rows_simple_kernel<bf16, HDV><<<grid, 256, 0, e->es>>>((const bf16*)qkv, (bf16*)out, M, d, text_len, scale); \
+    else attn_rows_simple_kernel<float, HDV><<<grid, 256, 0, e->es>>>((const float*)qkv, (float*)out, M, d, text_len, scale);      \
+    return VX_OK;                                                                                                                 \
+  }
+  AR(64) AR(32) AR(16) AR(8) AR(4)
+#undef AR
+  return fail(VX_ERR_UNSUPPORTED, "attention: head_dim %d", hd);
 }
 
 // One encoder stack over M rows held in e->X (valle.py:1035-1038 / 1125-1127).  `ada_stage` < 0:
@@ -656,7 +673,8 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
                      bool fill_cache, char* kv_base = nullptr) {
   if (kv_base == nullptr) kv_base = (char*)e->kv;
   const bool post = e->cfg.flags & VX_FLAG_POST_NORM;
-  const size_t kv_layer = (size_t)2 * H * e->ctx_max * 64 * e->esz;
+  const int hd = d / H;
+  const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd * e->esz;
   // The two N = d GEMMs of a layer (out-projection, FFN2) at M ~ 1k rows: 128^2 tiles alone are 72 workgroups, so K is
   // split over 2-4 workgroups per tile, every slice writes an fp32 slab, and the LayerNorm that follows the GEMM anyway
   // adds bias + slabs to x in a fixed order.  Larger M (batched rows) has enough tiles and adds in the GEMM epilogue.
@@ -683,8 +701,8 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
     } else if (fill_cache) {
       char* kc = kv_base + li * kv_layer;
       char* vc = kc + kv_layer / 2;
-      if (e->bf16) kv_scatter_kernel<bf16><<<M, 256, 0, e->es>>>((const bf16*)e->QKV, (bf16*)kc, (bf16*)vc, M, d, 64, e->ctx_max);
-      else kv_scatter_kernel<float><<<M, 256, 0, e->es>>>((const float*)e->QKV, (float*)kc, (float*)vc, M, d, 64, e->ctx_max);
+      if (e->bf16) kv_scatter_kernel<bf16><<<M, 256, 0, e->es>>>((const bf16*)e->QKV, (bf16*)kc, (bf16*)vc, M, d, hd, e->ctx_max);
+      else kv_scatter_kernel<float><<<M, 256, 0, e->es>>>((const float*)e->QKV, (float*)kc, (float*)vc, M, d, hd, e->ctx_max);
     }
     VXC(attn_rows(e, e->QKV, e->ATT, M, d, H, text_len));
     Fold fo;  // out-projection: x += out_proj(attn), folded into the norm that follows when split
@@ -917,7 +935,7 @@ extern "C" int vx_batch_prefill_all(vx_engine* e, int32_t n, const int64_t* cons
 // launch sequence (captured once as a hipGraph) serves every pass.
 static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
   const vx_config& c = e->cfg;
-  const int d = c.d_model, H = c.nhead, hd = 64;
+  const int d = c.d_model, H = c.nhead, hd = d / H;
   const bool post = c.flags & VX_FLAG_POST_NORM;
   SampleArgs sa{};
   sa.logits = e->ar_logits; sa.V = AR_VOCAB; sa.st = e->d_st;
@@ -964,8 +982,17 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     }
     if (pf_on) gemv_prefetch(a, l.out_w, d, d, e->bf16, e->num_cu);  // used two kernels later; the attention kernel reads no weights
     VXC(launch_gemv(e->bf16, a, e->num_cu, s));
-    if (e->bf16) attn_decode_kernel<bf16, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale);
-    else attn_decode_kernel<float, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale);
+#define AD(HDV)                                                                                                                                              \
+  if (hd == HDV) {                                                                                                                                           \
+    if (e->bf16) attn_decode_small_kernel<bf16, HDV><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale); \
+    else attn_decode_small_kernel<float, HDV><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale);      \
+  }
+    if (hd == 64) {
+      if (e->bf16) attn_decode_kernel<bf16, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale);
+      else attn_decode_kernel<float, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale);
+    }
+    AD(32) AD(16) AD(8) AD(4)
+#undef AD
     // x += out_proj(attn)
     GemvArgs o{};
     o.st = e->d_st; o.hd = hd; o.nhead = H;

@@ -286,13 +286,14 @@ __global__ __launch_bounds__(256) void attn_rows_simple_kernel(const T* __restri
     blk_limit = last < text_len ? text_len : last + 1;
   }
   float m = -INFINITY, l = 0.f;
-  const int lr = tid >> 2, lc = (tid & 3) * 16;
+  constexpr int CPT = HD / 4;  // channels each of a row's 4 loader threads copies
+  const int lr = tid >> 2, lc = (tid & 3) * CPT;
   for (int kt = 0; kt < blk_limit; kt += 64) {
     __syncthreads();
     {
       const int kr = kt + lr;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < CPT; ++j) {
         Ks[lr][lc + j] = (kr < M) ? to_f32(qkv[(size_t)kr * ld3 + d + h * HD + lc + j]) : 0.f;
         Vs[lr][lc + j] = (kr < M) ? to_f32(qkv[(size_t)kr * ld3 + 2 * d + h * HD + lc + j]) : 0.f;
       }

@@ -43,8 +43,15 @@ class VALLE:
             raise TypeError(f"unexpected arguments {sorted(kwargs)}")
         if (not norm_first or add_prenet) and self.engine_opts.get("max_batch", 0) > 1:
             raise NotImplementedError("norm_first=False / add_prenet=True run on the batch-1 path only (inference_batch needs the defaults)")
-        if self.cfg.num_quantizers > 1 and (self.cfg.nar_nhead <= 0 or self.cfg.nar_dim != 64 * self.cfg.nar_nhead):
-            raise NotImplementedError("nar_scale_factor must keep the NAR head_dim at 64 (DESIGN.md)")
+        # head_dim 64 is the tuned geometry; 4/8/16/32 (the reference's own test: decoder_dim 64, nhead 16, valle_test.py:93-95)
+        # run on the plain kernels, batch-1 only
+        hds = [d_model // nhead if nhead > 0 and d_model % nhead == 0 else 0]
+        if self.cfg.num_quantizers > 1:
+            hds.append(self.cfg.nar_dim // self.cfg.nar_nhead if self.cfg.nar_nhead > 0 and self.cfg.nar_dim % self.cfg.nar_nhead == 0 else 0)
+        if any(h not in (4, 8, 16, 32, 64) for h in hds):
+            raise NotImplementedError(f"head_dim must be 4, 8, 16, 32 or 64 (got {hds}; DESIGN.md)")
+        if any(h != 64 for h in hds) and self.engine_opts.get("max_batch", 0) > 1:
+            raise NotImplementedError("inference_batch needs head_dim 64")
         self.ar_audio_prepend_bos = self.cfg.prepend_bos
         self.num_quantizers = self.cfg.num_quantizers
         self.prefix_mode = prefix_mode
