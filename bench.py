@@ -204,8 +204,8 @@ def main():
                          "bytes_per_launch": int(step_bytes)},
         }
         if Bt == 1 and os.environ.get("VX_AR_PREFETCH", "1") != "0":
-            out["roofline"]["traffic_note"] = ("fabric read requests (FETCH_SIZE x2), ~2x algorithmic by design: each GEMV also requests the next "
-                                               "GEMV's weights so that they are served from the Infinity Cache; VX_AR_PREFETCH=0: 1.05x, -6% tokens/s")
+            out["roofline"]["traffic_note"] = ("fabric read requests (FETCH_SIZE x2), ~2x algorithmic by design: each GEMV also requests the weights of the GEMV "
+                                               "two places ahead so that they are served from the Infinity Cache; VX_AR_PREFETCH=0: 1.05x, -8% tokens/s")
         if world == 1 and not args.no_cpu_baseline:
             x, x_lens, y = utts[0]
             out["cpu_baseline"] = cpu_baseline(sd, cfg, x, x_lens, y, args.cpu_tokens)

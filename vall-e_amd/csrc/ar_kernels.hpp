@@ -43,9 +43,10 @@ struct GemvArgs {
   void* vcache;
   int d, hd, ctx_max, nhead;
   const ArState* st;
-  // NPF > 0: L2 warm-up for the NEXT kernel of the decode step.  Workgroup b touches bytes [b pf_slice, (b+1) pf_slice) of
-  // `pf` - the slice workgroup b of the next GEMV streams - so that kernel finds its weights in the L2 of the XCD
-  // it runs on (workgroups are placed round-robin over the 8 XCDs in both launches).  Speed only: the values are never used.
+  // NPF > 0: cache warm-up for a LATER GEMV of the decode step (engine.hip picks which: two places ahead).  Workgroup b
+  // touches bytes [b pf_slice, (b+1) pf_slice) of `pf` - the slice workgroup b of that GEMV streams.  The per-XCD L2s drop the
+  // lines at the kernel boundary; what the consumer gains is a hit in the memory-side Infinity Cache.  Speed only: the values
+  // are never used.
   const void* pf;
   unsigned pf_slice, pf_total;
 };

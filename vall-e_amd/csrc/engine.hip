@@ -751,7 +751,7 @@ static int sync_out(vx_engine* e, void* stream) {
 // Post-norm: there is no final norm; a prefill row is already norm2'd, the decode step's x still needs the last
 // layer's norm2 (fused here instead).
 static int enqueue_head(vx_engine* e, hipStream_t s, const float* x = nullptr, float* logits = nullptr,
-                        const ArState* st = nullptr, bool prefilled = false) {
+                        const ArState* st = nullptr, bool prefilled = false, const void* pfW = nullptr, int pfN = 0, int pfK = 0) {
   const vx_config& c = e->cfg;
   const bool post = c.flags & VX_FLAG_POST_NORM;
   GemvArgs a{};
@@ -764,6 +764,7 @@ static int enqueue_head(vx_engine* e, hipStream_t s, const float* x = nullptr, f
   a.N = AR_VOCAB; a.K = c.d_model;
   a.pro = (post && prefilled) ? PRO_COPY : PRO_LN; a.epi = EPI_LOGITS;
   a.st = st ? st : e->d_st;
+  if (pfW) gemv_prefetch(a, pfW, pfN, pfK, e->bf16, e->num_cu);  // decode step: the next token's first GEMVs
   return launch_gemv(e->bf16, a, e->num_cu, s);
 }
 
@@ -962,7 +963,21 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
   }
   const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd * e->esz;
   const float scale = 1.0f / sqrtf((float)hd);
-  static const bool pf_on = !(getenv("VX_AR_PREFETCH") && atoi(getenv("VX_AR_PREFETCH")) == 0);
+  // L2 / Infinity-Cache warm-up (GemvArgs.pf): GEMV i of the step also requests the weights of GEMV i + dist, in step order
+  // [QKV_0, out_0, FFN1_0, FFN2_0, QKV_1, ..., FFN2_{L-1}, head] and wrapping into the next token's step.
+  static const int pf_dist = getenv("VX_AR_PREFETCH") ? atoi(getenv("VX_AR_PREFETCH")) : 2;
+  struct PfW { const void* W; int N, K; };
+  std::vector<PfW> seq;
+  for (int li = 0; li < c.num_layers; ++li) {
+    const LayerW& l = e->ar_l[li];
+    seq.push_back({l.in_w, 3 * d, d}); seq.push_back({l.out_w, d, d}); seq.push_back({l.w1, 4 * d, d}); seq.push_back({l.w2, d, 4 * d});
+  }
+  seq.push_back({W<void>(e, "ar_predict_layer.weight"), AR_VOCAB, d});
+  auto warm = [&](GemvArgs& a, int idx) {
+    if (pf_dist <= 0) return;
+    const PfW& n = seq[(idx + pf_dist) % seq.size()];
+    gemv_prefetch(a, n.W, n.N, n.K, e->bf16, e->num_cu);
+  };
   for (int li = 0; li < c.num_layers; ++li) {
     const LayerW& l = e->ar_l[li];
     char* kc = (char*)e->kv + (size_t)li * kv_layer;
@@ -980,7 +995,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
       if (li == 0) { a.pro = PRO_COPY; }
       else { a.gamma = e->ar_l[li - 1].n2_g; a.beta = e->ar_l[li - 1].n2_b; a.xnorm_out = e->ar_xn; res = e->ar_xn; }
     }
-    if (pf_on) gemv_prefetch(a, l.out_w, d, d, e->bf16, e->num_cu);  // used two kernels later; the attention kernel reads no weights
+    warm(a, 4 * li);
     VXC(launch_gemv(e->bf16, a, e->num_cu, s));
 #define AD(HDV)                                                                                                                                              \
   if (hd == HDV) {                                                                                                                                           \
@@ -998,7 +1013,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     o.st = e->d_st; o.hd = hd; o.nhead = H;
     o.W = l.out_w; o.bias = l.out_b; o.part = e->ar_part; o.y = e->ar_x; o.N = d; o.K = d; o.pro = PRO_ATTN; o.epi = EPI_RESID;
     o.res = res;
-    if (pf_on) gemv_prefetch(o, l.w1, 4 * d, d, e->bf16, e->num_cu);
+    warm(o, 4 * li + 1);
     VXC(launch_gemv(e->bf16, o, e->num_cu, s));
     // f = relu(linear1(LN2(x)))
     GemvArgs f{};
@@ -1006,20 +1021,22 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     f.W = l.w1; f.bias = l.b1; f.x = e->ar_x; f.gamma = l.n2_g; f.beta = l.n2_b; f.y = e->ar_f;
     f.N = 4 * d; f.K = d; f.pro = PRO_LN; f.epi = EPI_RELU;
     if (post) { f.gamma = l.n1_g; f.beta = l.n1_b; f.xnorm_out = e->ar_xn; }  // x = norm1(x + sa(x)), kept in ar_xn
-    if (pf_on) gemv_prefetch(f, l.w2, d, 4 * d, e->bf16, e->num_cu);
+    warm(f, 4 * li + 2);
     VXC(launch_gemv(e->bf16, f, e->num_cu, s));
     // x += linear2(f)
     GemvArgs g{};
     g.st = e->d_st;
     g.W = l.w2; g.bias = l.b2; g.x = e->ar_f; g.y = e->ar_x; g.N = d; g.K = 4 * d; g.pro = PRO_COPY; g.epi = EPI_RESID;
     if (post) g.res = e->ar_xn;  // raw sum norm1(..) + ff(..); its norm2 runs in the next layer's (or the head's) prologue
-    if (pf_on) {
-      if (li + 1 < c.num_layers) gemv_prefetch(g, e->ar_l[li + 1].in_w, 3 * d, d, e->bf16, e->num_cu);
-      else gemv_prefetch(g, W<void>(e, "ar_predict_layer.weight"), AR_VOCAB, d, e->bf16, e->num_cu);
-    }
+    warm(g, 4 * li + 3);
     VXC(launch_gemv(e->bf16, g, e->num_cu, s));
   }
-  VXC(enqueue_head(e, s));
+  if (pf_dist > 0) {
+    const PfW& n = seq[(4 * c.num_layers + pf_dist) % seq.size()];
+    VXC(enqueue_head(e, s, nullptr, nullptr, nullptr, false, n.W, n.N, n.K));
+  } else {
+    VXC(enqueue_head(e, s));
+  }
   return VX_OK;
 }
 
