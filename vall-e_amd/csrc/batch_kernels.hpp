@@ -49,6 +49,19 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
   const int kbeg = kg * (K / a.kgroups) + wave * NS * 32;
   const bf16* wp = a.W + (size_t)min(n0 + c, a.N - 1) * K + kbeg + 8 * g;
   const bf16* ap = a.A + (size_t)c * K + kbeg + 8 * g;
+  // epilogue operands first (clamped, unconditional): fetched after the K loop they are one more exposed memory round trip
+  float bias_v = 0.f;
+  if (EPI == BE_QKV || EPI == BE_RELU) bias_v = a.bias[min(n0 + c, a.N - 1)];
+  int st_done[NH], st_row[NH];
+#pragma unroll
+  for (int u = 0; u < NH; ++u) {
+    st_done[u] = 0; st_row[u] = 0;
+    if (EPI == BE_QKV || EPI == BE_LOGITS) {
+      const int i = wave * NH + u, b = min(16 * (i >> 2) + 4 * g + (i & 3), a.B - 1);
+      st_done[u] = a.st[b].done;
+      if (EPI == BE_QKV) st_row[u] = a.st[b].row;
+    }
+  }
   bf16x8b_t wf[NS], af[NH][NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) wf[s] = *reinterpret_cast<const bf16x8b_t*>(wp + s * 32);
@@ -79,18 +92,18 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
     if (EPI == BE_PARTIAL) {
       a.part[((size_t)kg * BMAX + b) * a.N + n] = x;
     } else if (EPI == BE_RELU) {
-      a.f[(size_t)b * a.N + n] = (bf16)fmaxf(x + a.bias[n], 0.f);
+      a.f[(size_t)b * a.N + n] = (bf16)fmaxf(x + bias_v, 0.f);
     } else if (EPI == BE_LOGITS) {
-      if (!a.st[b].done) a.logits[(size_t)b * a.logits_stride + n] = x;
+      if (!st_done[u]) a.logits[(size_t)b * a.logits_stride + n] = x;
     } else {  // BE_QKV
-      const float v = x + a.bias[n];
+      const float v = x + bias_v;
       const int sec = n / a.d, ii = n - sec * a.d;
       if (sec == 0) {
         a.q[(size_t)b * a.d + ii] = v;
-      } else if (!a.st[b].done) {
+      } else if (!st_done[u]) {
         const int h = ii / a.hd, cc = ii - h * a.hd;
         bf16* base = a.kv + (size_t)b * a.kv_slot_stride + (sec == 2 ? a.kv_v_offset : 0);
-        base[((size_t)h * a.ctx_max + a.st[b].row) * a.hd + cc] = (bf16)v;
+        base[((size_t)h * a.ctx_max + st_row[u]) * a.hd + cc] = (bf16)v;
       }
     }
   }
