@@ -144,9 +144,14 @@ static bool poison_on() {
   static const bool on = [] { const char* v = getenv("VX_POISON"); return v && atoi(v) != 0; }();
   return on;
 }
+// Every fill below goes to the engine's stream: `es` is a non-blocking stream, a null-stream hipMemset is not ordered with the
+// kernels enqueued on it right afterwards (a fill landing late would wipe rows the first kernels had already written).
 static int dalloc(vx_engine* e, void** p, size_t bytes) {
   HIPC(hipMalloc(p, bytes ? bytes : 16));
-  if (poison_on()) HIPC(hipMemset(*p, 0xFF, bytes ? bytes : 16));
+  if (poison_on()) {  // debug mode: also finished before anything on another stream (weight uploads) can touch the block
+    HIPC(hipMemsetAsync(*p, 0xFF, bytes ? bytes : 16, e->es));
+    HIPC(hipStreamSynchronize(e->es));
+  }
   e->allocs.push_back(*p);
   return VX_OK;
 }
@@ -318,10 +323,10 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   VXC(dalloc(e, &e->ATT, n * dmax * e->esz));
   // rows between the segments of a concatenated batch are never written by attention but are read by the
   // out-projection: they must hold finite values (a NaN row would reach valid rows as 0 x NaN through its V^T column)
-  HIPC(hipMemset(e->ATT, 0, n * dmax * e->esz));
+  HIPC(hipMemsetAsync(e->ATT, 0, n * dmax * e->esz, e->es));
   e->vt_ld = ((e->n_max + 63) / 64) * 64 + 64;  // key-padded row length of V^T (16-byte aligned tiles)
   VXC(dalloc(e, &e->VT, (size_t)dmax * e->vt_ld * 2));
-  HIPC(hipMemset(e->VT, 0, (size_t)dmax * e->vt_ld * 2));  // padding keys must stay finite (they meet P = 0)
+  HIPC(hipMemsetAsync(e->VT, 0, (size_t)dmax * e->vt_ld * 2, e->es));  // padding keys must stay finite (they meet P = 0)
   VXC(dalloc(e, &e->FF, n * 4 * dmax * e->esz));
   VXC(dalloc_t(e, &e->yemb, (size_t)c.max_audio * dn));
   VXC(dalloc_t(e, &e->nar_logits, (size_t)c.max_audio * 1024));
@@ -342,7 +347,7 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
     VXC(dalloc_t(e, &e->pn_h2, n * PRENET_H));
     VXC(dalloc_t(e, &e->pn_text, (size_t)c.max_text * dmax));
     VXC(dalloc_t(e, &e->d_zero, 4));
-    HIPC(hipMemset(e->d_zero, 0, 16));
+    HIPC(hipMemsetAsync(e->d_zero, 0, 16, e->es));
     VXC(dalloc_t(e, &e->ar_e, d));
     VXC(dalloc_t(e, &e->ar_h1, PRENET_H));
     VXC(dalloc_t(e, &e->ar_h2, PRENET_H));
@@ -374,11 +379,11 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
     VXC(dalloc_t(e, &e->d_seg_len, (size_t)BMAX));
     VXC(dalloc_t(e, &e->d_seg_text, (size_t)BMAX));
     // MFMA A operands always read 32 rows: rows of unused slots must hold finite values
-    HIPC(hipMemset(e->bx, 0, (size_t)BMAX * d * 4));
-    HIPC(hipMemset(e->bh, 0, (size_t)BMAX * d * 2));
-    HIPC(hipMemset(e->batt, 0, (size_t)BMAX * d * 2));
-    HIPC(hipMemset(e->bff, 0, (size_t)BMAX * 4 * d * 2));
-    HIPC(hipMemset(e->bst, 0, (size_t)BMAX * sizeof(ArState)));
+    HIPC(hipMemsetAsync(e->bx, 0, (size_t)BMAX * d * 4, e->es));
+    HIPC(hipMemsetAsync(e->bh, 0, (size_t)BMAX * d * 2, e->es));
+    HIPC(hipMemsetAsync(e->batt, 0, (size_t)BMAX * d * 2, e->es));
+    HIPC(hipMemsetAsync(e->bff, 0, (size_t)BMAX * 4 * d * 2, e->es));
+    HIPC(hipMemsetAsync(e->bst, 0, (size_t)BMAX * sizeof(ArState), e->es));
   }
   if (c.num_quantizers > 1)
     VXC(dalloc_t(e, &e->ada, (size_t)(c.num_quantizers - 1) * (2 * c.nar_num_layers + 1) * 2 * dn));
@@ -387,6 +392,7 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
     Tensor& t = e->w[k];
     VXC(dalloc(e, &t.p, t.numel * (t.low ? 2 : 4)));
   }
+  HIPC(hipStreamSynchronize(e->es));  // the fills above are done before the caller's uploads (other streams) begin
   *out = e;
   return VX_OK;
 }
@@ -1443,7 +1449,7 @@ static int ensure_rows(vx_engine* e, size_t rows, size_t audio_rows, size_t text
   auto regrow = [&](void** p, size_t bytes) -> int {
     for (auto& q : e->allocs) if (q == *p) { (void)hipFree(q); q = nullptr; }
     HIPC(hipMalloc(p, bytes));
-    if (poison_on()) HIPC(hipMemset(*p, 0xFF, bytes));
+    if (poison_on()) { HIPC(hipMemsetAsync(*p, 0xFF, bytes, e->es)); HIPC(hipStreamSynchronize(e->es)); }
     e->allocs.push_back(*p);
     return VX_OK;
   };
@@ -1453,11 +1459,11 @@ static int ensure_rows(vx_engine* e, size_t rows, size_t audio_rows, size_t text
   VXC(regrow(&e->Hn, rows * dmax * e->esz));
   VXC(regrow(&e->QKV, rows * 3 * dmax * e->esz));
   VXC(regrow(&e->ATT, rows * dmax * e->esz));
-  HIPC(hipMemset(e->ATT, 0, rows * dmax * e->esz));  // padding rows between segments are never written: keep them finite
+  HIPC(hipMemsetAsync(e->ATT, 0, rows * dmax * e->esz, e->es));  // padding rows between segments are never written: keep them finite
   VXC(regrow(&e->FF, rows * 4 * dmax * e->esz));
   VXC(regrow(&e->VT, dmax * (size_t)e->vt_ld * 2));
-  HIPC(hipMemset(e->VT, 0, dmax * (size_t)e->vt_ld * 2));
-  HIPC(hipMemset(e->X, 0, rows * dmax * 4));
+  HIPC(hipMemsetAsync(e->VT, 0, dmax * (size_t)e->vt_ld * 2, e->es));
+  HIPC(hipMemsetAsync(e->X, 0, rows * dmax * 4, e->es));
   if (e->slab != nullptr) {  // keep the split-K path available for concatenated rows below the 256^2 threshold
     e->slab_rows = rows < 4095 ? (int)rows : 4095;
     VXC(regrow((void**)&e->slab, (size_t)4 * e->slab_rows * dmax * 4));
