@@ -1610,6 +1610,7 @@ extern "C" int vx_read_buffer(vx_engine* e, const char* name, void* dst, int64_t
   else if (n == "batch_sampled" && e->bmax > 1) { src = (const char*)e->bsamp; size = (int64_t)BMAX * e->btok_stride * 4; }
   else return fail(VX_ERR_ARG, "unknown buffer '%s'", name);
   if (off < 0 || nbytes < 0 || off + nbytes > size) return fail(VX_ERR_ARG, "read of '%s' out of range (%lld+%lld > %lld)", name, (long long)off, (long long)nbytes, (long long)size);
+  HIPC(hipStreamSynchronize(e->es));  // the copy below runs on the null stream, which the engine's non-blocking stream does not order with
   HIPC(hipMemcpy(dst, src + off, (size_t)nbytes, hipMemcpyDeviceToHost));
   return VX_OK;
 }
