@@ -53,15 +53,22 @@ struct GemvArgs {
 
 // y = W x (+epilogue).  One wave owns RPW rows at a time; a row is KCH 16-byte loads per lane;
 // lane l holds x[(c*64 + l)*VEC .. +VEC) for chunk c.
+// The operands of the kernel's FIRST loads (activation vector, LayerNorm affine, weights, sizes) are explicit leading
+// arguments: with the build's `-amdgpu-kernarg-preload-count` the dispatcher places them in SGPRs at wave launch (14 are
+// available), so those loads do not wait for a kernarg fetch - one memory round trip per wave otherwise.  hipcc does not
+// preload by-value structs, so GemvArgs alone would not qualify; everything else is read from it after the weight loads
+// are out.   xin = a.part for PRO_ATTN, a.x otherwise;  nk = (N << 16) | K.
 template <typename WT, int KCH, int RPW, int PRO, int NPF = 0>
-__global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
+__global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ W_, const float* __restrict__ xin,
+                                                   const float* __restrict__ gamma_, const float* __restrict__ beta_,
+                                                   unsigned nk, const GemvArgs a) {
   constexpr int VEC = Vec16<WT>::N;
   constexpr int V4 = VEC / 4;
   __shared__ __attribute__((aligned(16))) float xs[PRO == PRO_ATTN ? 1024 : 4];
-  const int K = a.K, N = a.N;
+  const int K = (int)(nk & 0xffffu), N = (int)(nk >> 16);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nwaves = gridDim.x * 4;
-  const WT* __restrict__ W = reinterpret_cast<const WT*>(a.W);
+  const WT* __restrict__ W = reinterpret_cast<const WT*>(W_);
   int g = blockIdx.x * 4 + wave;
 
   // ---- (A) small loads, issued first.  Every load is unconditional on a clamped (in-range)
@@ -77,10 +84,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       const int k = min((c * 64 + lane) * VEC, K - VEC);
 #pragma unroll
       for (int j = 0; j < V4; ++j) {
-        x4[c][j] = *reinterpret_cast<const float4*>(a.x + k + 4 * j);
+        x4[c][j] = *reinterpret_cast<const float4*>(xin + k + 4 * j);
         if (PRO == PRO_LN) {
-          g4[c][j] = *reinterpret_cast<const float4*>(a.gamma + k + 4 * j);
-          b4[c][j] = *reinterpret_cast<const float4*>(a.beta + k + 4 * j);
+          g4[c][j] = *reinterpret_cast<const float4*>(gamma_ + k + 4 * j);
+          b4[c][j] = *reinterpret_cast<const float4*>(beta_ + k + 4 * j);
         }
       }
     }
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   const int ka = min(tid * 4, K - 4);
   if (PRO == PRO_ATTN) {
     const int h = ka / a.hd, c = ka - h * a.hd;
-    const float* p = a.part + (size_t)h * ATT_NSPLIT * ATT_PSTRIDE;
+    const float* p = xin + (size_t)h * ATT_NSPLIT * ATT_PSTRIDE;
 #pragma unroll
     for (int s = 0; s < ATT_NSPLIT; ++s) {
       const float2 ml = *reinterpret_cast<const float2*>(p + s * ATT_PSTRIDE);
@@ -99,16 +106,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       po[s] = *reinterpret_cast<const float4*>(p + s * ATT_PSTRIDE + 4 + c);
     }
   }
-  // epilogue operands of this wave's first row group: lane r owns row r (clamped, masked at the store)
-  const bool has_bias = a.bias != nullptr, has_res = a.epi == EPI_RESID;  // wave-uniform
-  float e_bias = 0.f, e_res = 0.f;
-  {
-    const int rc = min(g * RPW + min(lane, RPW - 1), N - 1);
-    if (has_bias) e_bias = a.bias[rc];
-    if (has_res) e_res = (a.res ? a.res : a.y)[rc];
-  }
-  int st_row = 0, st_pass = 0, st_trace = 0, st_done = 0, st_S = 0;
-  if (a.st) { st_row = a.st->row; st_pass = a.st->pass; st_trace = a.st->trace_logits; st_done = a.st->done; st_S = a.st->S; }
 
   // ---- (B) weight stream of the first row group (rows/k clamped; x is zero where k >= K) ----
   uint4 w[RPW][KCH];
@@ -124,6 +121,20 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     }
   };
   issue(g);
+  __builtin_amdgcn_sched_barrier(0);
+  // epilogue operands of this wave's first row group: lane r owns row r (clamped, masked at the store).  They come from
+  // the by-value struct, i.e. behind a kernarg fetch: placed after the weight loads, in front of the warm-up loads (the
+  // epilogue's wait must not cover those)
+  const float* __restrict__ bias_ = a.bias;
+  const float* rsrc = a.epi == EPI_RESID ? (a.res ? a.res : a.y) : nullptr;
+  const ArState* __restrict__ st_ = a.st;
+  const bool has_bias = bias_ != nullptr, has_res = rsrc != nullptr;  // wave-uniform
+  float e_bias = 0.f, e_res = 0.f;
+  {
+    const int rc = min(g * RPW + min(lane, RPW - 1), N - 1);
+    if (has_bias) e_bias = bias_[rc];
+    if (has_res) e_res = rsrc[rc];
+  }
   // next kernel's weights, behind this kernel's own stream (vmcnt retires in order: the waits below do not cover them)
   uint4 pfv[NPF > 0 ? NPF : 1];
   if (NPF > 0) {
@@ -136,6 +147,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   // pin the weight loads HERE: without this the scheduler sinks them below the prologue, next to
   // their first use, and the HBM round trip is serialised behind the LayerNorm
   __builtin_amdgcn_sched_barrier(0);
+  // decode state (scalar loads, used by the epilogues only): after the warm-up loads, so that the wait for the warm-up's
+  // own arguments does not also wait for these
+  int st_row = 0, st_pass = 0, st_trace = 0, st_done = 0, st_S = 0;
+  if (st_) { st_row = st_->row; st_pass = st_->pass; st_trace = st_->trace_logits; st_done = st_->done; st_S = st_->S; }
 
   // ---- (C) activation prologue in registers ---------------------------------------------------
   float xr[KCH][VEC];
@@ -271,8 +286,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     if (g * RPW >= N) break;
     {
       const int rc = min(g * RPW + min(lane, RPW - 1), N - 1);
-      if (has_bias) e_bias = a.bias[rc];
-      if (has_res) e_res = (a.res ? a.res : a.y)[rc];
+      if (has_bias) e_bias = bias_[rc];
+      if (has_res) e_res = rsrc[rc];
     }
     issue(g);
     rows();

@@ -28,6 +28,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
            "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+           # kernel arguments (the first 16 SGPRs' worth of explicit ones) arrive in registers at wave launch instead of by an
+           # s_load the kernel's first instructions wait for: 0.3 us per dependent kernel of the decode step
+           "-mllvm", "-amdgpu-kernarg-preload-count=16",
            "-o", OUT] + [os.path.join(HERE, s) for s in SRCS]
     if os.environ.get("VX_SAVE_TEMPS"):
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
@@ -41,7 +44,7 @@ def build_stamps() -> str:
     """Probe build with in-kernel phase stamps (common.hpp VX_STAMP) -> libvallex_stamps.so; never loaded by the package."""
     out = os.path.join(HERE, "libvallex_stamps.so")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-DVX_STAMPS",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-DVX_STAMPS", "-mllvm", "-amdgpu-kernarg-preload-count=16",
            "-Wno-unused-function", "-Wno-unused-variable", "-o", out] + [os.path.join(HERE, s) for s in SRCS]
     subprocess.check_call(cmd, cwd=HERE)
     return out

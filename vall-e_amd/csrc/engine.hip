@@ -529,8 +529,11 @@ extern "C" int vx_finalize_weights(vx_engine* e) {
 // ------------------------------------------------------------------------------ launch helpers
 template <typename WT, int KCH, int RPW, int PRO>
 static void launch_gemv_inst(const GemvArgs& a, int grid, hipStream_t s) {
-  if (a.pf != nullptr) gemv_kernel<WT, KCH, RPW, PRO, 8><<<grid, 256, 0, s>>>(a);
-  else gemv_kernel<WT, KCH, RPW, PRO, 0><<<grid, 256, 0, s>>>(a);
+  // leading arguments = what the kernel loads from first (kernarg preload, ar_kernels.hpp)
+  const float* xin = PRO == PRO_ATTN ? a.part : a.x;
+  const unsigned nk = ((unsigned)a.N << 16) | (unsigned)a.K;  // N, K < 65536 (checked by the caller: K <= 4096, N <= 4 d)
+  if (a.pf != nullptr) gemv_kernel<WT, KCH, RPW, PRO, 8><<<grid, 256, 0, s>>>(a.W, xin, a.gamma, a.beta, nk, a);
+  else gemv_kernel<WT, KCH, RPW, PRO, 0><<<grid, 256, 0, s>>>(a.W, xin, a.gamma, a.beta, nk, a);
 }
 
 // The instance for (N, K): KCH = 16-byte chunks per lane per row, RPW = rows per wave so that one
@@ -557,6 +560,7 @@ static void gemv_prefetch(GemvArgs& a, const void* Wn, int Nn, int Kn, bool bf, 
 template <typename WT, int PRO> static int launch_gemv_p(const GemvArgs& a, int num_cu, hipStream_t s) {
   constexpr int VEC = Vec16<WT>::N;
   if (a.K % VEC || a.K > 4096 || a.K % 4) return fail(VX_ERR_UNSUPPORTED, "gemv: K=%d unsupported", a.K);
+  if (a.N <= 0 || a.N > 65535) return fail(VX_ERR_UNSUPPORTED, "gemv: N=%d unsupported", a.N);  // (N << 16) | K travels as one argument
   const GemvPlan pl = gemv_plan(a.N, a.K, VEC, num_cu);
   const int kch = pl.kch, rpw = pl.rpw, grid = pl.grid;
   if (kch > 16 || (PRO != PRO_COPY && (kch > 4 || a.K > 1024))) return fail(VX_ERR_UNSUPPORTED, "gemv: K=%d too large for prologue %d", a.K, PRO);
