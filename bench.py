@@ -2,154 +2,292 @@
 """Headline benchmark: BASELINE.json configs[1] — d=1024 nhead=16 L=12 bf16, batch-1 AR top-k(10)
 decode + 7 NAR stages of a 10 s utterance (S=47 phonemes, 3 s prompt -> 753 frames x 8 codebooks).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
 
-One "step" = one whole VALLE.inference() (prefill + 753 AR passes + 7 NAR stages) of one utterance
-per GPU.  Utterances are independent, so N GPUs run N replicas (weak scaling): rank 0 owns the
-inputs, scatters them over RCCL, every rank decodes its own, codes are gathered back; scatter and
-gather are inside the timed region.  Prints ONE JSON line on rank 0.
+``--gpus N`` with N > 1 starts N ranks itself (one fresh process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in their environment, before this process has touched HIP) and relays rank 0's line; under
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` the ranks already exist and
+this file runs as one of them.  Either way WORLD_SIZE must equal --gpus.
+
+One "step" = one whole VALLE.inference() (prefill + 753 AR passes + 7 NAR stages) of one utterance per GPU;
+with ``--batch B`` one step = B utterances per GPU decoded together (BASELINE configs[2]: B = 32, ragged
+S in [40, 54]; configs[3] = ``--batch 32 --gpus 8``, 256 utterances per step).  Utterances are independent,
+so N GPUs run N replicas (weak scaling): rank 0 owns the inputs, sorts them by length, scatters them over RCCL,
+every rank decodes its own, codes are gathered back; scatter and gather are inside the timed region.
+Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 S_TEXT, P_PROMPT, TOP_K, TEMP = 47, 225, 10, 1.0
+D_MODEL, N_HEAD, N_LAYER = 1024, 16, 12
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+METRIC = "AR codec-tokens/sec/GPU + NAR 7-stage p50 latency, d=1024 L=12 10s utterance"
 
 
-def ar_bytes_per_token(d: int, L: int, ctx: float, bpe: int = 2) -> float:
-    """weights streamed once per token + KV cache read + KV write."""
-    weights = (L * (12 * d * d + 13 * d) + 2 * d + 1025 * d) * bpe
-    return weights + 2 * L * d * bpe * (ctx + 1)
+def weight_bytes(d: int, L: int, bpe: int) -> int:
+    """parameters one AR token streams (12 d^2 + 13 d per layer, final norm, 1025-way head)."""
+    return (L * (12 * d * d + 13 * d) + 2 * d + 1025 * d) * bpe
 
 
-def measured_traffic(ctx_mean: float):
-    """HBM bytes per AR step from the committed PMC profile (profiles/r01_pmc_ar_step.json: FETCH_SIZE x2 as the
-    microarch guide prescribes for gfx950, split into the ctx-independent GEMV part and the per-cached-row
-    attention part so that it can be quoted at this run's mean context).  None if the profile is absent."""
-    off = os.environ.get("VX_AR_PREFETCH", "1") == "0"  # the engine's weight warm-up doubles the fabric requests (see the profile's "reading")
-    path = os.path.join(ROOT, "profiles", "r01_pmc_ar_step_prefetch_off.json" if off else "r01_pmc_ar_step.json")
-    if not os.path.isfile(path):
-        return None
-    p = json.load(open(path))
-    return int(p["gemv_bytes_per_step_corrected"] + p["attn_bytes_per_ctx_row_corrected"] * ctx_mean)
+def kv_bytes_per_row(d: int, L: int, bpe: int) -> int:
+    return 2 * L * d * bpe  # K and V of every layer: 49 152 B at cfg1 in bf16
 
 
-def cpu_baseline(sd, cfg, x, x_lens, y, n_tokens: int):
-    """The reference algorithm (no KV cache, fp32, oracle/valle_oracle.inference_faithful — a checked
-    port, kind="port") on a bounded sample of the same workload, timed on this box's host cores."""
+def decode_bytes(launches: int, lens, bpe: int) -> float:
+    """Algorithmic bytes of `launches` decode steps over the utterances `lens` = [(S, P, T), ...] that share them: the
+    weights once per step + every live utterance's cached rows read and one row written (ctx = S + P + t at step t)."""
+    kv = kv_bytes_per_row(D_MODEL, N_LAYER, bpe)
+    total = float(launches) * weight_bytes(D_MODEL, N_LAYER, bpe)
+    for S, P, T in lens:
+        total += kv * (T * (S + P + 1) + T * (T - 1) / 2.0)
+    return total
+
+
+def committed_traffic():
+    """HBM traffic per batch-1 AR step from the newest committed PMC summary (profiles/r*_pmc_ar_step.json: FETCH_SIZE x2 per the
+    microarch guide's gfx950 correction, a SEPARATE rocprofv3 --pmc pass, not this run).  (value at ctx, source) or (None, None)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_ar_step.json")))
+    if not files or os.environ.get("VX_AR_PREFETCH", "") == "0":
+        return None, None
+    p = json.load(open(files[-1]))
+    return p, os.path.relpath(files[-1], ROOT)
+
+
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, cfg, x, x_lens, y, n_tokens: int, n_tokens_1t: int):
+    """The reference algorithm (no KV cache, fp32, oracle/valle_oracle.inference_faithful — a checked port, kind="port") on a
+    bounded sample of the same workload, timed on this box's host cores: once on all the cores this process may use and once
+    on ONE thread (what the reference's CLI does: torch.set_num_threads(1), valle/bin/infer.py:262-263)."""
+    import torch
     from oracle import valle_oracle as vo  # checker / baseline only — never the product path
 
     m = vo.OracleModel(sd, cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, cfg.prefix_mode, cfg.prepend_bos,
                        cfg.num_quantizers)
-    threads = torch.get_num_threads()
-    t0 = time.time()
-    codes = vo.inference_faithful(m, x, x_lens, y, None, TOP_K, TEMP, exp_noise=torch.ones(n_tokens + 2, 1025),
-                                  max_new_tokens=n_tokens)
-    dt = time.time() - t0
+    ctx0 = S_TEXT + P_PROMPT
+
+    def run(threads, n):
+        torch.set_num_threads(threads)
+        t0 = time.time()
+        codes = vo.inference_faithful(m, x, x_lens, y, None, TOP_K, TEMP, exp_noise=torch.ones(n + 2, 1025), max_new_tokens=n)
+        dt = time.time() - t0
+        return codes.shape[1] / dt, dt
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    before = torch.get_num_threads()
+    v_all, dt_all = run(cores, n_tokens)
+    v_one, dt_one = run(1, n_tokens_1t)
+    torch.set_num_threads(before)
+    tail = "fp32, no KV cache; later AR steps cost more (O(T^2)), so the full-length CPU rate is lower than this"
     return {
-        "value": round(codes.shape[1] / dt, 3), "unit": "codec-tokens/s", "cores": threads, "kind": "port",
-        "sample": f"first {n_tokens} of 753 AR steps (no KV cache, ctx {S_TEXT + P_PROMPT}..{S_TEXT + P_PROMPT + n_tokens}) + "
-                  f"7 NAR stages over {S_TEXT + P_PROMPT + n_tokens} rows, fp32, {dt:.1f} s wall; later AR steps cost more "
-                  "(O(T^2)), so the full-length CPU rate is lower than this",
+        "value": round(v_all, 3), "unit": "codec-tokens/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
+        "sample": f"first {n_tokens} of 753 AR steps (ctx {ctx0}..{ctx0 + n_tokens}) + 7 NAR stages over {ctx0 + n_tokens} rows, "
+                  f"{dt_all:.1f} s wall on {cores} threads; {tail}",
+        "one_thread": {"value": round(v_one, 3), "unit": "codec-tokens/s", "cores": 1,
+                       "sample": f"first {n_tokens_1t} AR steps + 7 NAR stages over {ctx0 + n_tokens_1t} rows, {dt_one:.1f} s wall, "
+                                 "torch.set_num_threads(1) as valle/bin/infer.py:262-263 does"},
     }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--precision", default="bf16", help="bf16 | fp32 (the token-exact parity mode) | fp8nar (bf16 AR, fp8 NAR GEMMs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=16)
+    ap.add_argument("--cpu-tokens-1t", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1, help="utterances decoded together per GPU per step (1 = the headline "
-                    "batch-1 workload, BASELINE configs[1]; 32 = configs[2]/[3])")
+                    "batch-1 workload, BASELINE configs[1]; 32 = configs[2], with --gpus 8 configs[3]; 64 + --precision fp8nar + "
+                    "--text-len 94 = configs[4])")
+    ap.add_argument("--uniform", action="store_true", help="--batch > 1: every utterance S = --text-len instead of the ragged mix")
+    ap.add_argument("--text-len", type=int, default=S_TEXT, help="phonemes per utterance (47 -> 753 frames = 10 s; 94 -> 1505 = 20 s)")
     ap.add_argument("--no-graph", action="store_true", help="launch the AR step kernel by kernel (rocprofv3 --pmc cannot follow hipGraph replays)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run-cpu", action="store_true", help="tests only: gloo on CPU with a stand-in decoder, to exercise the "
+                    "launcher / partition / scatter / gather path without a GPU; the line says so in `data`")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args, argv) -> int:
+    """Parent of an N-rank run.  Starts N fresh interpreters BEFORE anything here has touched HIP (this process never does),
+    relays rank 0's JSON line, fails if any rank fails."""
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if any(rcs) or line is None:
+        print(f"bench.py: ranks exited with {rcs}; no result line" if line is None else f"bench.py: ranks exited with {rcs}", file=sys.stderr)
+        return 1
+    rec = json.loads(line)
+    if rec.get("n_gpus") != n:
+        print(f"bench.py: result line says n_gpus={rec.get('n_gpus')}, asked for {n}", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------ one rank
+class _DryRunModel:
+    """--dry-run-cpu: stands in for the engine so that the launcher / sharding path runs on CPU (tests).  Output length follows
+    the reference's natural length 16 S + 1 (valle.py:1047); the codes are a checksum of the inputs."""
+
+    def inference(self, x, x_lens, y, enroll, top_k=-100, temperature=1.0):
+        import torch
+
+        T = 16 * int(x_lens[0]) + 1
+        base = (y[0].sum(0) + x.sum()) % 1024
+        return ((base.reshape(1, 1, -1) + torch.arange(T).reshape(1, T, 1)) % 1024).to(torch.int64)
+
+    def inference_batch(self, utts, top_k=-100, temperature=1.0, seeds=None):
+        return [self.inference(u[0], u[1], u[2], None) for u in utts]
+
+    def timings(self):
+        return dict(prefill_ms=0.0, decode_ms=1.0, nar_ms=0.0, n_pass=1, launches=1, batch_decode_ms=1.0, batch_launches=1)
+
+
+def run_rank(args) -> int:
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+        return 2
+    dry = args.dry_run_cpu
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+    if dry:
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
 
-    import __graft_entry__ as ge
-
-    if rank == 0:
-        ge.build()
-    if world > 1:
-        dist.barrier()
     from valle_amd.config import ModelConfig
-    from valle_amd.models import VALLE
-    from valle_amd.sharding import gather_codes, scatter_utterances
+    from valle_amd.sharding import gather_lists, plan_partition, scatter_lists
     from valle_amd.weights import synthetic_inputs, synthetic_state_dict
 
-    cfg = ModelConfig(decoder_dim=1024, nhead=16, num_decoder_layers=12, prefix_mode=1)
-    sd = synthetic_state_dict(cfg, seed=0)
-    model = VALLE(1024, 16, 12, prefix_mode=1, precision=args.precision, max_text=64, max_audio=1024, print_eos=False,
-                  no_graph=args.no_graph, max_batch=args.batch if args.batch > 1 else 0)
-    model.load_state_dict(sd)
-    model.to(dev).eval()
-    eng = model.engine()
+    cfg = ModelConfig(decoder_dim=D_MODEL, nhead=N_HEAD, num_decoder_layers=N_LAYER, prefix_mode=1)
+    Bt = args.batch
+    ragged = Bt > 1 and not args.uniform
+    s_of = (lambda i: args.text_len - 7 + (i % 15)) if ragged else (lambda i: args.text_len)  # 40..54 around 47 (SURVEY §8(d) cfg2)
+    s_max = args.text_len + 7 if ragged else args.text_len
+    sd = None
+    if dry:
+        model, eng = _DryRunModel(), None
+    else:
+        import __graft_entry__ as ge
 
-    n_total = args.warmup + args.steps
-    # rank 0 owns every utterance of the job: (world * n_total) independent inputs
-    utts = None
-    if rank == 0:
-        utts = [synthetic_inputs(S_TEXT, P_PROMPT, 8, seed=1 + i) for i in range(world * n_total * args.batch)]
-
-    def run_phase(step_ids):
-        """scatter -> decode -> gather for the utterances of these steps; returns #frames produced here."""
-        Bt = args.batch
-        mine = scatter_utterances([utts[(s * world + r) * Bt + j] for s in step_ids for j in range(Bt) for r in range(world)]
-                                  if rank == 0 else None, len(step_ids) * Bt, dev, world, rank)
-        outs, frames = [], 0
-        tms = []
-        if Bt > 1:
-            for i in range(len(step_ids)):
-                group = mine[i * Bt : (i + 1) * Bt]
-                res = model.inference_batch(group, top_k=TOP_K, temperature=TEMP,
-                                            seeds=[1234 + (step_ids[i] * world + rank) * Bt + j for j in range(Bt)])
-                outs += res
-                frames += sum(c.shape[1] for c in res)
-                tms.append(eng.timings())
-        else:
-            for i, (x, x_lens, y) in enumerate(mine):
-                torch.manual_seed(1234 + step_ids[i] * world + rank)  # seeds the on-device sampler
-                codes = model.inference(x, x_lens, y, None, top_k=TOP_K, temperature=TEMP)
-                outs.append(codes)
-                frames += codes.shape[1]
-                tms.append(eng.timings())
-        gather_codes(outs, dev, world, rank)
-        return frames, outs, tms
-
-    def fence():
-        torch.cuda.synchronize(dev)
+        if rank == 0:
+            ge.build()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        from valle_amd.models import VALLE
 
-    run_phase(list(range(args.warmup)))
+        sd = synthetic_state_dict(cfg, seed=0)
+        max_audio = ((P_PROMPT + 16 * s_max + 2 + 63) // 64) * 64
+        model = VALLE(D_MODEL, N_HEAD, N_LAYER, prefix_mode=1, precision=args.precision, max_text=max(64, s_max), max_audio=max_audio,
+                      print_eos=False, no_graph=args.no_graph, max_batch=Bt if Bt > 1 else 0)
+        model.load_state_dict(sd)
+        model.to(dev).eval()
+        eng = model.engine()
+
+    n_total = args.warmup + args.steps
+    per_step = world * Bt
+    utts = None
+    if rank == 0:  # rank 0 owns every utterance of the job
+        utts = [synthetic_inputs(s_of(i), P_PROMPT, 8, seed=1 + i) for i in range(n_total * per_step)]
+
+    def run_phase(first_step, n_steps):
+        """partition -> scatter -> decode -> gather for the utterances of these steps; returns (#frames made here, codes in
+        utterance order on rank 0, per-group engine timings, per-group (S, P, T))."""
+        lists = plan = None
+        if rank == 0:
+            mine_all = utts[first_step * per_step : (first_step + n_steps) * per_step]
+            plan = plan_partition([u[0].shape[1] for u in mine_all], world, Bt)
+            lists = [[mine_all[i] for i in idx] for idx in plan]
+        mine = scatter_lists(lists, n_steps * Bt, dev, world, rank)
+        outs, frames, tms, shapes = [], 0, [], []
+        for i in range(n_steps):
+            group = mine[i * Bt : (i + 1) * Bt]
+            seed0 = 1234 + ((first_step + i) * world + rank) * Bt
+            if Bt > 1:
+                res = model.inference_batch(group, top_k=TOP_K, temperature=TEMP, seeds=[seed0 + j for j in range(Bt)])
+            else:
+                torch.manual_seed(seed0)  # seeds the on-device sampler
+                res = [model.inference(group[0][0], group[0][1], group[0][2], None, top_k=TOP_K, temperature=TEMP)]
+            outs += res
+            frames += sum(c.shape[1] for c in res)
+            tms.append((eng or model).timings())
+            shapes.append([(u[0].shape[1], u[2].shape[1], c.shape[1]) for u, c in zip(group, res)])
+        got = gather_lists(outs, dev, world, rank)
+        ordered = None
+        if got is not None:
+            ordered = [None] * (n_steps * per_step)
+            for r, idx in enumerate(plan):
+                for j, i in enumerate(idx):
+                    ordered[i] = got[r][j]
+        return frames, ordered, tms, shapes
+
+    def fence():
+        if not dry:
+            torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        if not dry:
+            torch.cuda.synchronize(dev)
+
+    if args.warmup:
+        run_phase(0, args.warmup)
     fence()
     t0 = time.perf_counter()
-    frames, outs, tms = run_phase(list(range(args.warmup, n_total)))
+    frames, outs, tms, shapes = run_phase(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt, float(frames)], dtype=torch.float64, device=dev)
@@ -159,59 +297,67 @@ def main():
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, frames = float(tmax[0]), float(tsum[1])
-    # HIP-event device times (engine stream) of every timed step on this rank: totals for the AR step, p50 for NAR
-    import statistics
-    tm = dict(tms[-1])
-    for k in ("decode_ms", "launches", "batch_decode_ms", "batch_launches"):
-        tm[k] = sum(t[k] for t in tms)
-    tm["nar_ms"] = statistics.median(t["nar_ms"] for t in tms)
-    tm["prefill_ms"] = statistics.median(t["prefill_ms"] for t in tms)
 
     if rank == 0:
-        T = outs[-1].shape[1]
-        ctx_mean = S_TEXT + P_PROMPT + (T - 1) / 2.0
-        bpe = 2 if args.precision == "bf16" else 4
-        Bt = args.batch
-        if Bt > 1:  # batched step: weights once + Bt KV streams
-            step_s = tm["batch_decode_ms"] * 1e-3 / max(1, tm["batch_launches"])
-            step_bytes = ar_bytes_per_token(1024, 12, 0, bpe) + Bt * 2 * 12 * 1024 * bpe * ctx_mean
-            tm = dict(tm, decode_ms=tm["batch_decode_ms"], launches=tm["batch_launches"] * Bt)
-        else:
-            step_s = tm["decode_ms"] * 1e-3 / max(1, tm["launches"])
-            step_bytes = ar_bytes_per_token(1024, 12, ctx_mean, bpe)
+        bpe = 4 if args.precision == "fp32" else 2
+        # HIP-event device times (engine stream) of every timed group on this rank: totals for the AR step, p50 for NAR / prefill
+        dkey, lkey = ("batch_decode_ms", "batch_launches") if Bt > 1 else ("decode_ms", "launches")
+        decode_ms = sum(t_[dkey] for t_ in tms)
+        launches = sum(t_[lkey] for t_ in tms)
+        step_s = decode_ms * 1e-3 / max(1, launches)
+        total_bytes = sum(decode_bytes(t_[lkey], sh, bpe) for t_, sh in zip(tms, shapes))
+        step_bytes = total_bytes / max(1, launches)
         achieved = step_bytes / step_s / 1e9
+        ar_tokens = sum(T for sh in shapes for (_, _, T) in sh)
+        T_show = shapes[-1][0][2]
+        if Bt == 1:
+            workload = (f"BASELINE configs[1]: d=1024 nhead=16 L=12, batch=1 AR top-k(10) + 7 NAR stages, S={args.text_len} P={P_PROMPT} -> "
+                        f"T={T_show} frames x 8 codebooks, one utterance per GPU per step")
+        else:
+            tag = "configs[3]" if (Bt == 32 and world == 8) else "configs[2]" if Bt == 32 else "configs[4]" if (Bt == 64 and args.precision == "fp8nar") else "configs[2] geometry at another batch size"
+            mix = (f"S in [{args.text_len - 7}, {args.text_len + 7}] (T = 16 S + 1 = {16 * (args.text_len - 7) + 1}..{16 * (args.text_len + 7) + 1}, mean {16 * args.text_len + 1})"
+                   if ragged else f"S={args.text_len} -> T={T_show}")
+            workload = (f"BASELINE {tag}: d=1024 nhead=16 L=12, batch={Bt} concurrent utterances per GPU (padded KV, hipGraph step, one batched "
+                        f"prefill and one batched NAR pass per step), {mix}, P={P_PROMPT}, x 8 codebooks; {world * Bt} utterances per step")
         out = {
-            "metric": "AR codec-tokens/sec/GPU + NAR 7-stage p50 latency, d=1024 L=12 10s utterance",
+            "metric": METRIC,
             "value": round(frames / dt, 2), "unit": "codec-tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[1]: d=1024 nhead=16 L=12, batch=1 AR top-k(10) + 7 NAR stages, "
-                                    f"S={S_TEXT} P={P_PROMPT} -> T={T} frames x 8 codebooks, one utterance per GPU per step")
-                       if Bt == 1 else
-                       (f"BASELINE configs[2]{'' if Bt == 32 else ' geometry at another batch size'}: d=1024 nhead=16 L=12, batch={Bt} concurrent utterances per GPU (padded KV, "
-                        f"hipGraph step, one batched prefill and one batched NAR pass), S={S_TEXT} P={P_PROMPT} -> T={T} x 8"),
-                       "parallelism": f"replica x{world} (utterance sharding, RCCL scatter/gather)"},
-            "ar_tokens_per_s": round(tm["launches"] / (tm["decode_ms"] * 1e-3), 1),
+            "vs_baseline": None, "dtype": {"fp32": "f32", "fp8nar": "bf16 (AR) + fp8 e4m3 GEMM operands (NAR)"}.get(args.precision, args.precision),
+            "data": "synthetic" if not dry else "dry-run: no engine (launcher / sharding test on CPU)",
+            "config": {"workload": workload, "parallelism": f"replica x{world} (utterances sorted by length, sharded, RCCL scatter/gather)"},
+            "ar_tokens_per_s": round(ar_tokens / (decode_ms * 1e-3), 1),
             "ar_step_us": round(step_s * 1e6, 2),
-            "prefill_ms": round(tm["prefill_ms"], 3),
-            "nar_7stage_ms": round(tm["nar_ms"], 3),  # p50 over the timed steps
-            "roofline": {"bound": "hbm", "kernel": "AR decode step (hipGraph of 62 kernels = 1 token)" if Bt == 1 else
-                         f"batched AR decode step (hipGraph of 87 kernels = {Bt} tokens)",
+            "prefill_ms": round(statistics.median(t_["prefill_ms"] for t_ in tms), 3),
+            "nar_7stage_ms": round(statistics.median(t_["nar_ms"] for t_ in tms), 3),  # p50 over the timed groups
+            "roofline": {"bound": "hbm", "kernel": "AR decode step (hipGraph of one token's kernels)" if Bt == 1 else
+                         f"batched AR decode step (hipGraph, {Bt} slots)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(ctx_mean) if (args.precision == "bf16" and Bt == 1) else None,
-                         "bytes_per_launch": int(step_bytes)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(step_bytes)},
         }
-        if Bt == 1 and os.environ.get("VX_AR_PREFETCH", "1") != "0":
-            out["roofline"]["traffic_note"] = ("fabric read requests (FETCH_SIZE x2), ~2x algorithmic by design: each GEMV also requests the weights of the GEMV "
-                                               "two places ahead so that they are served from the Infinity Cache; VX_AR_PREFETCH=0: 1.05x, -8% tokens/s")
-        if world == 1 and not args.no_cpu_baseline:
-            x, x_lens, y = utts[0]
-            out["cpu_baseline"] = cpu_baseline(sd, cfg, x, x_lens, y, args.cpu_tokens)
+        if Bt == 1 and args.precision == "bf16" and not dry:
+            prof, src = committed_traffic()
+            if prof is not None:
+                ctx_mean = args.text_len + P_PROMPT + (T_show - 1) / 2.0
+                out["roofline"]["traffic"] = int(prof["gemv_bytes_per_step_corrected"] + prof["attn_bytes_per_ctx_row_corrected"] * ctx_mean)
+                out["roofline"]["traffic_source"] = (f"{src}: FETCH_SIZE x2 from a separate rocprofv3 --pmc pass of an eager (no-graph) run, "
+                                                     "quoted at this run's mean context; NOT measured in this run")
+        if world == 1 and not args.no_cpu_baseline and not dry:
+            x, x_lens, y = synthetic_inputs(S_TEXT, P_PROMPT, 8, seed=1)
+            out["cpu_baseline"] = cpu_baseline(sd, cfg, x, x_lens, y, args.cpu_tokens, args.cpu_tokens_1t)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

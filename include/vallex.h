@@ -34,7 +34,8 @@ enum vx_status {
   VX_ERR_ARG = 1,         /* bad argument (the reference would trip an assert, valle.py:986-991) */
   VX_ERR_HIP = 2,         /* a HIP runtime call failed */
   VX_ERR_STATE = 3,       /* call order violated (e.g. decode before prefill) */
-  VX_ERR_CAPACITY = 4,    /* S / P / T exceed the capacities given at vx_create */
+  VX_ERR_CAPACITY = 4,    /* S / P / T exceed the capacities given at vx_create, or a decode filled the KV cache (max_audio
+                             rows) before the reference's stop rule fired; the worst case 16 S + 1 alone is NOT refused */
   VX_ERR_UNSUPPORTED = 5, /* configuration outside the built scope */
   VX_ERR_WEIGHTS = 6      /* unknown key, wrong shape or missing tensor */
 };
@@ -106,7 +107,7 @@ void vx_destroy(vx_engine* e);
  * at a time.  `key` is the reference state_dict key, `data` fp32 (host or device), row-major. */
 int vx_set_weight(vx_engine* e, const char* key, const float* data, const int64_t* shape, int32_t ndim);
 /* Optional: the fp32 sine table of SinePositionalEmbedding (modules/embedding.py:75-88),
- * (rows, dim).  which: 0 = AR width, 1 = NAR width.  If never set, the engine fills it with
+ * (rows, dim) with rows >= max(4000, max_text + max_audio).  which: 0 = AR width, 1 = NAR width.  If never set, the engine fills it with
  * host sinf/cosf (same formula; may differ from torch's table in the last ulp). */
 int vx_set_sine_table(vx_engine* e, int32_t which, const float* data, int64_t rows, int64_t dim);
 /* strict=True check (every key present) + model.eval(); precomputes the per-stage AdaptiveLayerNorm
@@ -132,6 +133,14 @@ int vx_ar_result(vx_engine* e, int64_t* tokens, int32_t capacity, int32_t* n_tok
  * codes_out: (T, Q) int64 row-major, column 0 = ar_tokens (valle.py:1136-1137). */
 int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
            const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream);
+/* vx_nar / vx_nar_continual (continual != 0) with two parity-test options.  forced_codes (optional, (T, Q) int64): stage i
+ * still reports its own argmax in codes_out[:, i+1], but the embedding fed to the later stages (valle.py:1133-1134) is taken from
+ * forced_codes[:, i+1] - with the reference's codes this gives every stage exactly the input the reference gave it, so bf16 / fp8
+ * engines can be compared stage by stage.  stage_logits (optional, (Q-1, T, 1024) fp32, host or device): the logits rows of every
+ * stage (valle.py:1128). */
+int vx_nar_ex(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
+              const int64_t* ar_tokens, int32_t T, int64_t* codes_out, const int64_t* forced_codes, float* stage_logits,
+              int32_t continual, void* stream);
 /* VALLE.continual's NAR body (valle.py:1185-1236): same arguments as vx_nar.  Differs from vx_nar only for models with
  * prenets in prefix mode 0, where continual() applies the audio position BEFORE the audio prenet (valle.py:1193-1194). */
 int vx_nar_continual(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
@@ -161,6 +170,11 @@ int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_nar, const 
                  const int64_t* const* prompts, const int32_t* P, const int64_t* const* ar_tokens, const int32_t* T,
                  int64_t* const* codes_out, void* stream);
 
+/* vx_nar_batch with per-stage teacher forcing: forced_codes[i] = (T_i, Q) int64 as in vx_nar_ex, or forced_codes == NULL. */
+int vx_nar_batch_ex(vx_engine* e, int32_t n, const int64_t* const* text_nar, const int32_t* S2,
+                    const int64_t* const* prompts, const int32_t* P, const int64_t* const* ar_tokens, const int32_t* T,
+                    int64_t* const* codes_out, const int64_t* const* forced_codes, void* stream);
+
 /* Device-time of the last calls, measured with HIP events on the engine's stream:
  * out[0] prefill ms, out[1] AR decode ms, out[2] NAR ms, out[3] AR passes, out[4] graph launches. */
 int vx_get_timings(vx_engine* e, double* out, int32_t n);
@@ -169,8 +183,9 @@ int vx_get_timings(vx_engine* e, double* out, int32_t n);
  * names: "ar_logits" (n_pass x 1025 fp32 with VX_FLAG_TRACE_LOGITS, else the last row),
  * "ar_sampled" / "ar_argmax" (int32 per pass), "nar_logits" (T x 1024 fp32 of the last stage),
  * "ar_x" (d fp32 residual stream of the last AR row), "nar_x" (N x d fp32 after the last stage),
- * "batch_logits" (32 x 1088 fp32: newest logits row of every slot), "batch_argmax" / "batch_sampled"
- * (32 x (max_audio+2) int32 per pass). */
+ * "batch_logits" (64 x 1088 fp32: newest logits row of every slot), "batch_argmax" / "batch_sampled"
+ * (64 x (max_audio+2) int32 per pass), "batch_trace" (max_batch x (max_audio+2) x 1025 fp32: every pass's logits row of every
+ * slot, engines created with VX_FLAG_TRACE_LOGITS and max_batch > 1). */
 int vx_read_buffer(vx_engine* e, const char* name, void* dst, int64_t offset_bytes, int64_t nbytes);
 
 /* Kernel-level entry points (device pointers, fp32 unless noted) used by tests/ to check each
@@ -188,21 +203,6 @@ int vx_op_attention(int32_t prec, int32_t use_mfma, const void* qkv, void* out, 
 int vx_op_sample(const float* logits, int32_t V, int32_t top_k, float temperature, const float* exp_noise,
                  int32_t* out_token_argmax /* [2]: sampled, argmax */, void* stream);
 int vx_op_convert_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
-
-/* Measurement aid for DESIGN.md's launch-boundary budget: us per kernel of a dependent chain of
- * n trivial kernels, out[0] replayed as a hipGraph, out[1] launched eagerly. */
-int vx_debug_launch_floor(int32_t n_kernels, int32_t grid, int32_t block, int32_t iters, double* out);
-/* Probe for a single-launch decode step: `stages` dependent 1024-wide GEMV stages in ONE kernel, separated by a
- * device-wide barrier (mode 0 = barrier only, 1 = release/acquire fences, 2 = agent-scope loads/stores + counter, 3 = as 2 with the barrier among groups of 8 consecutive workgroups only, 4 = among the workgroups with equal blockIdx % 8: timing, results unchecked).
- * rows in {4,12,16} = output rows per workgroup per stage.  out[0] us/launch, out[1] us/stage, out[2] max |err|
- * against a host evaluation of the same chain, out[3] != 0 when a bounded spin ran out. */
-int vx_debug_stage_chain(int32_t nwg, int32_t stages, int32_t rows, int32_t mode, int32_t iters, double* out);
-/* Probe: L2 -> CU fill rate.  `grid` workgroups of `threads` lanes stream one shared region of `region_bytes` with `unroll`
- * independent 16-byte loads in flight per lane.  out[0] GB/s chip-wide, out[1] bytes/clock per busy CU, out[2] clock (GHz). */
-int vx_debug_l2_fill(int32_t grid, int32_t threads, int32_t unroll, int64_t region_bytes, int32_t iters, double* out);
-/* Probe builds only (csrc/build.py --stamps -> libvallex_stamps.so): phase timestamps (10 ns ticks) that workgroup 0 of the
- * last stamped kernel recorded at its VX_STAMP points.  The product library returns VX_ERR_UNSUPPORTED. */
-int vx_debug_read_stamps(unsigned long long* out, int32_t n);
 
 #ifdef __cplusplus
 }

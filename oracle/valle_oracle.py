@@ -342,7 +342,8 @@ class ArCache:
             x, (k, v) = encoder_layer(L, x, m.nhead, mask, None, m.norm_first)
             self.k.append(k)
             self.v.append(v)
-        return m.ar_logits(m.ar_final_norm(x[-1:]))
+        self.last_h = m.ar_final_norm(x[-1:])  # input of the predict layer (tests craft EOS rows from it)
+        return m.ar_logits(self.last_h)
 
     def step(self, token: torch.Tensor) -> torch.Tensor:
         """token: (1,) int64 — the audio token appended at audio position ``n_audio``."""
@@ -367,7 +368,8 @@ class ArCache:
             else:
                 x = L.norm(0, x, None)
                 x = L.norm(1, x + F.linear(F.relu(F.linear(x, L.w1, L.b1)), L.w2, L.b2), None)
-        return m.ar_logits(m.ar_final_norm(x))
+        self.last_h = m.ar_final_norm(x)
+        return m.ar_logits(self.last_h)
 
 
 @torch.no_grad()
@@ -391,6 +393,7 @@ def inference_cached(m: OracleModel, x, x_lens, y, enroll_x_lens=None, top_k: in
     while True:
         if trace is not None:
             trace.setdefault("ar_logits", []).append(logits[0].clone())
+            trace.setdefault("ar_hidden", []).append(cache.last_h[0].clone())
         noise = None if exp_noise is None else exp_noise[step : step + 1]
         samples = topk_sampling(logits, top_k, temperature, noise)
         if trace is not None:

@@ -80,3 +80,25 @@ def golden_cache():
         return cache[name]
 
     return get
+
+
+class NarStats:
+    """tests/golden/narstats/<name>.npz (oracle/gen_nar_stats.py): per-stage logit statistics of the unmodified reference for
+    every generated row (top-1 / top-2 values, largest magnitude) and the full logits of a few rows."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, "narstats", name + ".npz"))
+        self.top1 = torch.from_numpy(z["top1"])          # (Q-1, T)
+        self.top2 = torch.from_numpy(z["top2"])
+        self.absmax = torch.from_numpy(z["absmax"])
+        self.rows = torch.from_numpy(z["rows"].astype(np.int64))
+        self.row_logits = torch.from_numpy(z["row_logits"])  # (Q-1, len(rows), 1024)
+
+    def decided(self, rel_tol):
+        """(Q-1, T) bool: rows whose reference decision margin exceeds twice the tolerance (rel_tol x the row's logit scale):
+        there the index selection must be exact (north_star: bit-exact argmax wherever the margin allows)."""
+        return (self.top1 - self.top2) > 2 * rel_tol * self.absmax
+
+
+def nar_stats_available(name):
+    return os.path.isfile(os.path.join(GOLDEN, "narstats", name + ".npz"))

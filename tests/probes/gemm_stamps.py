@@ -7,7 +7,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 hip = C.CDLL("libamdhip64.so")
-lib = C.CDLL(os.path.join(ROOT, "vall-e_amd", "csrc", "libvallex_stamps.so"))
+lib = C.CDLL(os.path.join(ROOT, "vall-e_amd", "csrc", "libvallex_stamps.so"))  # build.py --stamps
 lib.vx_last_error.restype = C.c_char_p
 lib.vx_op_gemm.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]
 lib.vx_debug_read_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int32]

@@ -3,8 +3,9 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-import __graft_entry__ as ge
-ge.build()
+import valle_amd  # noqa
+from valle_amd.engine import load_probe_library
+load_probe_library()  # libvallex_probes.so: `python vall-e_amd/csrc/build.py --probes`
 from conftest import Golden
 from valle_amd.models import VALLE
 

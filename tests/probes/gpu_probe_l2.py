@@ -2,6 +2,8 @@
 import json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import valle_amd  # noqa
+from valle_amd.engine import load_probe_library
+load_probe_library()  # libvallex_probes.so: `python vall-e_amd/csrc/build.py --probes`
 from valle_amd.engine import l2_fill
 
 for region in (2 << 20, 32 << 20, 1 << 30):

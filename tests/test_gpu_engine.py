@@ -142,15 +142,60 @@ def test_bf16_engine_teacher_forced(name, simple):
         top2 = ref.topk(2)[0]
         if float(top2[0] - top2[1]) > 2 * tol:
             assert int(got_all[s].argmax()) == int(ref.argmax())
-    # NAR: same AR tokens in, per-stage argmax agreement against the reference codes
-    codes = e.nar(text if g.cfg.prefix_mode not in (2, 4) else torch.cat([text[:1], text[int(g.enroll_x_lens.max()) - 1:]]),
-                  prompts, forced).cpu()
+    # NAR: every stage is fed the reference's codes of the earlier stages (forced_codes), so each stage sees exactly the
+    # reference's input and rounding cannot compound; per-stage argmax agreement against the reference codes (the margin
+    # rule proper is test_nar_stages_teacher_forced_margin_rule)
+    text_nar = text if g.cfg.prefix_mode not in (2, 4) else torch.cat([text[:1], text[int(g.enroll_x_lens.max()) - 1:]])
+    codes = e.nar(text_nar, prompts, forced, forced_codes=g.codes[0]).cpu()
     if g.cfg.num_quantizers > 1:
-        agree = (codes[:, 1:] == g.codes[0, :, 1:]).float().mean().item()
-        first = (codes[:, 1] == g.codes[0, :, 1]).float().mean().item()
-        # stage 1 sees identical inputs; later stages inherit earlier flips, so only stage 1 is bounded tightly
-        assert first >= 0.90, first
-        assert agree >= 0.60, agree
+        per_stage = (codes[:, 1:] == g.codes[0, :, 1:]).float().mean(0)
+        print(name, "simple" if simple else "mfma", "AR worst rel err %.4f" % worst, "NAR agreement per stage", [round(float(v), 4) for v in per_stage])
+        assert float(per_stage.min()) >= 0.93, per_stage
+
+
+NAR_REL_TOL = 0.03  # bf16 operands through L layers, as a fraction of a logits row's largest magnitude (same as the AR side)
+
+
+@pytest.mark.parametrize("name,precision", [("tiny_mode0", "fp32"), ("tiny_mode0", "bf16"), ("cfg0_topk10", "bf16"),
+                                            ("cfg1_topk10", "bf16")])
+def test_nar_stages_teacher_forced_margin_rule(name, precision):
+    """North-star rule on the NAR side, for the precision the benchmark runs: every stage is fed the reference's own codes of
+    the earlier stages (vx_nar_ex forced_codes: exactly the input the reference gave that stage, valle.py:1133-1134), so
+    rounding cannot compound across stages.  Per stage and row: the engine's argmax must equal the reference's wherever the
+    reference's top-2 margin exceeds 2 x tolerance; the logits of the recorded rows must lie within the tolerance; overall
+    agreement is bounded from below by what is measured (not by the margin rule alone)."""
+    from conftest import NarStats
+
+    g = Golden(name)
+    ns = NarStats(name)
+    m = _model(g, precision)
+    e = m.engine()
+    Q = g.cfg.num_quantizers
+    text, prompts = g.x[0], g.y[0, :, :Q].contiguous()
+    ref = g.codes[0]
+    codes, lg = e.nar(text, prompts, ref[:, 0].contiguous(), forced_codes=ref, stage_logits=True)
+    codes = codes.cpu()
+    assert torch.equal(codes[:, 0], ref[:, 0])
+    rel = 1e-5 if precision == "fp32" else NAR_REL_TOL
+    # (a) logits of the recorded rows within the tolerance
+    worst = 0.0
+    for i in range(Q - 1):
+        err = (lg[i, ns.rows] - ns.row_logits[i]).abs().amax(1)
+        scale = ns.absmax[i, ns.rows]
+        worst = max(worst, float((err / scale).max()))
+        assert bool((err <= rel * scale + 1e-6).all()), (i, float((err / scale).max()))
+    # (b) index selection exact wherever the reference's margin exceeds 2 x tolerance
+    eq = (codes[:, 1:] == ref[:, 1:]).t()  # (Q-1, T)
+    decided = ns.decided(rel)
+    assert bool(eq[decided].all()), f"{int((~eq[decided]).sum())} decided rows flipped"
+    # (c) plain agreement, per stage
+    per_stage = eq.float().mean(1)
+    print(name, precision, "worst rel err %.4f" % worst, "decided %.3f" % float(decided.float().mean()),
+          "agreement per stage", [round(float(v), 4) for v in per_stage])
+    if precision == "fp32":
+        assert bool(eq.all())
+    else:
+        assert float(per_stage.min()) >= 0.95, per_stage
 
 
 @pytest.mark.parametrize("name", golden_names("continual"))
@@ -164,8 +209,14 @@ def test_continual_matches_reference(name, precision):
     assert torch.equal(codes[..., 0], g.codes[..., 0])
     if precision == "fp32":
         assert torch.equal(codes, g.codes)  # bit-exact
-    else:
-        assert (codes == g.codes).float().mean() >= 0.85
+    else:  # bf16: stage by stage on the reference's inputs (vx_nar_ex, continual = 1)
+        prefix_len = min(int(g.y.shape[1] * 0.5), 3 * 75)
+        forced = g.codes[0]
+        c2 = m.engine().nar(g.x[0], g.y[0, :prefix_len, :8].contiguous(), g.y[0, prefix_len:, 0].contiguous(), continual=True,
+                            forced_codes=forced).cpu()
+        per_stage = (c2[:, 1:] == forced[:, 1:]).float().mean(0)
+        print(name, "continual bf16 agreement per stage", [round(float(v), 4) for v in per_stage])
+        assert float(per_stage.min()) >= 0.93, per_stage
 
 
 # ---- stop rule, exceptions and ragged sizes (valle.py:1044-1057) against the oracle ---------------------
@@ -225,25 +276,64 @@ def test_eos_at_first_pass_raises_syntax_error_like_the_reference():
         m.inference(x.cuda(), xl.cuda(), y.cuda(), None, top_k=-100, exp_noise=noise)
 
 
-def test_eos_by_argmax(monkeypatch=None):
+def test_eos_by_argmax():
+    """valle.py:1045: the loop stops when argmax(logits) == EOS, whatever the sample is.  The EOS row of the predict layer is
+    crafted from the oracle's own final hidden state of pass k (logit_EOS(j) = alpha h_k . h_j), so that EOS is the argmax at
+    pass k and at no earlier pass, while the noise makes the multinomial draw token 3 at every pass (sample != EOS): only the
+    argmax branch can stop the decode.  Engine == oracle, stop reason VX_STOP_EOS_ARGMAX."""
     from valle_amd.weights import synthetic_inputs
 
     cfg, sd, m = _tiny()
-    w = sd["ar_predict_layer.weight"]
-    w.zero_()
+    x, xl, y = synthetic_inputs(5, 8)
+    noise = torch.ones(16 * 5 + 2, 1025)
+    noise[:, 3] = 1e-9  # p[3] / q[3] dwarfs every other ratio: token 3 is sampled at every pass
+    vo, om = _oracle(cfg, sd)
+    tr = {}
+    full = vo.inference_cached(om, x, xl, y, None, -100, 1.0, noise, trace=tr, skip_nar=True)
+    assert full.shape[1] == 81 and bool((full[0, :, 0] == 3).all())
+    H = torch.stack(tr["ar_hidden"])                 # (passes, d): independent of the predict layer
+    top = torch.stack(tr["ar_logits"])[:, :1024].max(1)[0]  # best non-EOS logit of every pass
+    k = alpha = None
+    for cand in range(4, 30):
+        a = float(top[cand] + 1.0) / float(H[cand] @ H[cand])
+        eos = a * (H[: cand + 1] @ H[cand])
+        if bool((eos[:cand] < top[:cand] - 0.5).all()) and float(eos[cand]) > float(top[cand]) + 0.5:
+            k, alpha = cand, a
+            break
+    assert k is not None, "no pass found whose hidden state separates from the earlier ones"
+    sd["ar_predict_layer.weight"][1024] = alpha * H[k]
+    vo, om = _oracle(cfg, sd)
+    want = vo.inference_cached(om, x, xl, y, None, -100, 1.0, noise)
+    assert want.shape == (1, k, 8)  # passes 0..k-1 appended a token, pass k stopped by argmax
     m.load_state_dict(sd)
     m.to("cuda:0").eval()
-    x, xl, y = synthetic_inputs(5, 8)
-    # make EOS the arg-max from some pass on: logits = W h with W[1024] = c * (final-LN output of that pass) is
-    # data dependent, so instead force it through ties: all logits equal -> argmax is index 0, never EOS; check that
-    # the engine agrees with the oracle on the full natural length in that degenerate case
+    got = m.inference(x.cuda(), xl.cuda(), y.cuda(), None, top_k=-100, exp_noise=noise).cpu()
+    assert torch.equal(got, want)
+    e = m.engine()
+    assert e.ar_result()[1] == 1  # VX_STOP_EOS_ARGMAX
+    n_pass = k + 1
+    assert int(e.read("ar_argmax", (n_pass,), dtype=torch.int32)[k]) == 1024
+    assert int(e.read("ar_sampled", (n_pass,), dtype=torch.int32)[k]) == 3  # the sample was NOT EOS
+
+
+def test_long_text_is_not_refused_by_the_worst_case_bound():
+    """The stop rule's worst case (16 S + 1 tokens, valle.py:1047) may exceed max_audio as long as the decode really stops
+    earlier (a trained model stops at EOS): S = 31, P = 200 needs 200 + 497 rows in the worst case, the cache has 600, EOS is
+    sampled at pass 9.  Only a decode that fills the cache is a capacity error (test_capacity_and_index_errors_are_loud)."""
+    from valle_amd.weights import synthetic_inputs
+
+    cfg, sd, m = _tiny()
+    sd["ar_predict_layer.weight"].zero_()
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    x, xl, y = synthetic_inputs(31, 200)
+    noise = torch.ones(100, 1025)
+    noise[:, 5] = 0.5
+    noise[9, 1024] = 1e-3
     vo, om = _oracle(cfg, sd)
-    noise = torch.ones(16 * 5 + 2, 1025)
-    noise[:, 17] = 0.25
     want = vo.inference_cached(om, x, xl, y, None, -100, 1.0, noise)
     got = m.inference(x.cuda(), xl.cuda(), y.cuda(), None, top_k=-100, exp_noise=noise).cpu()
-    assert want.shape == (1, 81, 8) and torch.equal(got, want)
-    assert m.engine().ar_result()[1] == 3  # VX_STOP_LENGTH
+    assert want.shape == (1, 9, 8) and torch.equal(got, want)
 
 
 @pytest.mark.parametrize("S,P", [(1, 1), (2, 33), (31, 3)])

@@ -35,7 +35,10 @@ def _worker(rank, world, port, per_rank, q):
 
     utts = _utts(world * per_rank) if rank == 0 else None
     res = infer_sharded(_fake_decode, utts, per_rank, torch.device("cpu"), world, rank)
+    res_b = infer_sharded(None, utts, per_rank, torch.device("cpu"), world, rank, group=3,
+                          run_many=lambda us: [_fake_decode(*u) for u in us])  # one padded batch of 3 per rank
     if rank == 0:
+        assert all(torch.equal(a, b) for a, b in zip(res, res_b))
         q.put([r.clone() for r in res])
     else:
         assert res is None
@@ -72,3 +75,46 @@ def test_single_rank_passthrough():
     res = infer_sharded(_fake_decode, utts, 3, torch.device("cpu"), 1, 0)
     for a, u in zip(res, utts):
         assert torch.equal(a, _fake_decode(*u))
+
+
+def test_partition_sorts_by_length_and_balances():
+    """sort by S, contiguous groups (tight batches), summed cost evened out over the ranks."""
+    from valle_amd.sharding import plan_partition
+
+    lens = [40 + (i * 7) % 15 for i in range(64)]
+    plan = plan_partition(lens, world=4, group=4)
+    assert sorted(i for idx in plan for i in idx) == list(range(64))  # a permutation
+    assert all(len(idx) == 16 for idx in plan)
+    for idx in plan:
+        for k in range(0, 16, 4):  # every group is a contiguous run of the sorted order: spread <= what 4 neighbours span
+            g = [lens[i] for i in idx[k : k + 4]]
+            assert max(g) - min(g) <= 1
+    cost = [sum(lens[i] for i in idx) for idx in plan]
+    assert max(cost) - min(cost) <= 4
+    import pytest
+
+    with pytest.raises(ValueError):
+        plan_partition(lens[:10], world=4, group=4)
+
+
+def test_bench_launcher_spawns_ranks_on_gloo():
+    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) must start two ranks itself and print ONE line with
+    n_gpus == 2; --dry-run-cpu swaps the engine for a stand-in so that this runs without a GPU (gloo).  The 2 x 4 x 3
+    utterances go through plan_partition / scatter / gather exactly as on the GPUs."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["data"].startswith("dry-run")
+    frames = sum(16 * (40 + (i % 15)) + 1 for i in range(8, 24))  # the 16 utterances of the two timed steps
+    assert abs(rec["value"] * rec["ms_per_step"] * 2e-3 - frames) < 0.01 * frames
+    # a rank count that disagrees with --gpus is refused
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0

@@ -32,6 +32,8 @@ struct BgemmArgs {
   float* part;        // BE_PARTIAL: (kgroups, 32, N)
   float* logits;      // BE_LOGITS: (32, logits_stride)
   int logits_stride;
+  float* trace;       // BE_LOGITS, optional (VX_FLAG_TRACE_LOGITS): (slots, trace_rows, N) - row `pass` of every live slot
+  int trace_rows;
 };
 
 // C[b][n] = sum_k A[b][k] W[n][k] on v_mfma_f32_16x16x32_bf16: one workgroup = one 16-row n tile (x one K
@@ -52,14 +54,14 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
   // epilogue operands first (clamped, unconditional): fetched after the K loop they are one more exposed memory round trip
   float bias_v = 0.f;
   if (EPI == BE_QKV || EPI == BE_RELU) bias_v = a.bias[min(n0 + c, a.N - 1)];
-  int st_done[NH], st_row[NH];
+  int st_done[NH], st_row[NH];  // st_row: KV row (BE_QKV) / pass index of the logits row being produced (BE_LOGITS trace)
 #pragma unroll
   for (int u = 0; u < NH; ++u) {
     st_done[u] = 0; st_row[u] = 0;
     if (EPI == BE_QKV || EPI == BE_LOGITS) {
       const int i = wave * NH + u, b = min(16 * (i >> 2) + 4 * g + (i & 3), a.B - 1);
       st_done[u] = a.st[b].done;
-      if (EPI == BE_QKV) st_row[u] = a.st[b].row;
+      st_row[u] = EPI == BE_QKV ? a.st[b].row : a.st[b].pass;
     }
   }
   bf16x8b_t wf[NS], af[NH][NS];
@@ -94,7 +96,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
     } else if (EPI == BE_RELU) {
       a.f[(size_t)b * a.N + n] = (bf16)fmaxf(x + bias_v, 0.f);
     } else if (EPI == BE_LOGITS) {
-      if (!st_done[u]) a.logits[(size_t)b * a.logits_stride + n] = x;
+      if (!st_done[u]) {
+        a.logits[(size_t)b * a.logits_stride + n] = x;
+        if (a.trace != nullptr && st_row[u] < a.trace_rows) a.trace[((size_t)b * a.trace_rows + st_row[u]) * a.N + n] = x;
+      }
     } else {  // BE_QKV
       const float v = x + bias_v;
       const int sec = n / a.d, ii = n - sec * a.d;

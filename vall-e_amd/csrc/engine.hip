@@ -20,7 +20,6 @@ __device__ unsigned long long g_vx_stamps[32];
 #include "rows_kernels.hpp"
 #include "mfma_kernels.hpp"
 #include "batch_kernels.hpp"
-#include "persist_probe.hpp"
 
 using namespace vx;
 
@@ -48,6 +47,21 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 extern "C" const char* vx_last_error(void) { return g_err.c_str(); }
+
+// Every entry point runs on the engine's device and leaves the caller's current device as it found it.
+struct DevGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DevGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+    else if (err == hipSuccess) prev = -1;  // already current: nothing to restore
+  }
+  ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define ON_DEVICE(dev)   \
+  DevGuard dev_guard_(dev); \
+  HIPC(dev_guard_.err)
 
 // ------------------------------------------------------------------------------ engine state
 struct Tensor {
@@ -101,9 +115,10 @@ struct vx_engine {
   int vt_ld = 0;
   float *yemb = nullptr, *nar_logits = nullptr, *ada = nullptr;
   long long *ids_text = nullptr, *ids_audio = nullptr, *ids_prompts = nullptr, *ids_samples = nullptr, *d_codes = nullptr;
+  long long* d_fcodes = nullptr;  // teacher-forced NAR stages (vx_nar_ex): the caller's (T, Q) codes
   // batched decode (slots)
   int bmax = 0;
-  float *bx = nullptr, *bq = nullptr, *bpart = nullptr, *blogits = nullptr;
+  float *bx = nullptr, *bq = nullptr, *bpart = nullptr, *blogits = nullptr, *btrace = nullptr;
   vx::bf16 *bh = nullptr, *batt = nullptr, *bff = nullptr, *bkv = nullptr;
   size_t bkv_slot = 0;  // elements per slot
   ArState* bst = nullptr;    // device, BMAX
@@ -247,6 +262,8 @@ static void host_sine_table(std::vector<float>& t, int rows, int d) {
 }
 
 // ------------------------------------------------------------------------------ create/destroy
+static int create_body(vx_engine* e);
+extern "C" void vx_destroy(vx_engine* e);
 extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   if (!cfg || !out) return fail(VX_ERR_ARG, "null argument");
   if (cfg->struct_size != (int32_t)sizeof(vx_config)) return fail(VX_ERR_ARG, "vx_config.struct_size mismatch");
@@ -276,9 +293,23 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   if (c.max_batch > 1 && (c.precision != VX_PREC_BF16 || c.d_model % 128))
     return fail(VX_ERR_UNSUPPORTED, "batched decode needs bf16 precision and d_model % 128 == 0");
 
-  HIPC(hipSetDevice(c.device));
+  ON_DEVICE(c.device);
   vx_engine* e = new vx_engine();
   e->cfg = c;
+  const int rc = create_body(e);
+  if (rc != VX_OK) {  // g_err holds the failing call; release whatever was allocated up to it
+    const std::string keep = g_err;
+    vx_destroy(e);
+    g_err = keep;
+    return rc;
+  }
+  *out = e;
+  return VX_OK;
+}
+
+static int create_body(vx_engine* e) {
+  const vx_config& c = e->cfg;
+  const bool hd64 = c.d_model / c.nhead == 64 && (c.num_quantizers == 1 || c.nar_d_model / c.nar_nhead == 64);
   e->bf16 = c.precision == VX_PREC_BF16;
   e->hd64 = hd64;
   e->esz = e->bf16 ? 2 : 4;
@@ -335,6 +366,7 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   VXC(dalloc_t(e, &e->ids_prompts, (size_t)c.max_audio * 8));
   VXC(dalloc_t(e, &e->ids_samples, (size_t)c.max_audio));
   VXC(dalloc_t(e, &e->d_codes, (size_t)c.max_audio * 8));
+  VXC(dalloc_t(e, &e->d_fcodes, (size_t)c.max_audio * 8));
   e->cap_audio = c.max_audio; e->cap_text = c.max_text;
   if (e->bf16 && !(c.flags & VX_FLAG_SIMPLE_ROWS)) {
     e->slab_rows = e->n_max < 4095 ? e->n_max : 4095;
@@ -364,6 +396,8 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
     VXC(dalloc_t(e, &e->bq, (size_t)BMAX * d));
     VXC(dalloc_t(e, &e->bpart, (size_t)4 * BMAX * d));
     VXC(dalloc_t(e, &e->blogits, (size_t)BMAX * LOGITS_CUR));
+    if (c.flags & VX_FLAG_TRACE_LOGITS)  // parity tests: every pass's logits row of every slot
+      VXC(dalloc_t(e, &e->btrace, (size_t)e->bmax * (c.max_audio + 2) * AR_VOCAB));
     VXC(dalloc_t(e, &e->bh, (size_t)BMAX * d));
     VXC(dalloc_t(e, &e->batt, (size_t)BMAX * d));
     VXC(dalloc_t(e, &e->bff, (size_t)BMAX * 4 * d));
@@ -393,13 +427,12 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
     VXC(dalloc(e, &t.p, t.numel * (t.low ? 2 : 4)));
   }
   HIPC(hipStreamSynchronize(e->es));  // the fills above are done before the caller's uploads (other streams) begin
-  *out = e;
   return VX_OK;
 }
 
 extern "C" void vx_destroy(vx_engine* e) {
   if (!e) return;
-  (void)hipSetDevice(e->cfg.device);
+  DevGuard dev_guard_(e->cfg.device);
   if (e->es) (void)hipStreamSynchronize(e->es);
   for (auto& kvp : e->bgraphs) (void)hipGraphExecDestroy(kvp.second);
   if (e->h_bst) (void)hipHostFree(e->h_bst);
@@ -420,7 +453,7 @@ extern "C" void vx_destroy(vx_engine* e) {
 // ------------------------------------------------------------------------------ weights
 extern "C" int vx_set_weight(vx_engine* e, const char* key, const float* data, const int64_t* shape, int32_t ndim) {
   if (!e || !key || !data || !shape) return fail(VX_ERR_ARG, "null argument");
-  HIPC(hipSetDevice(e->cfg.device));
+  ON_DEVICE(e->cfg.device);
   auto it = e->w.find(key);
   if (it == e->w.end()) return fail(VX_ERR_WEIGHTS, "unexpected key '%s'", key);
   Tensor& t = it->second;
@@ -446,9 +479,9 @@ extern "C" int vx_set_weight(vx_engine* e, const char* key, const float* data, c
 
 extern "C" int vx_set_sine_table(vx_engine* e, int32_t which, const float* data, int64_t rows, int64_t dim) {
   if (!e || !data) return fail(VX_ERR_ARG, "null argument");
-  HIPC(hipSetDevice(e->cfg.device));
+  ON_DEVICE(e->cfg.device);
   const int d = which == 0 ? e->cfg.d_model : e->cfg.nar_d_model;
-  if (dim != d || rows < e->ctx_max) return fail(VX_ERR_ARG, "sine table must be (>= %d, %d)", e->ctx_max, d);
+  if (dim != d || rows < e->pe_rows) return fail(VX_ERR_ARG, "sine table must be (>= %d, %d)", e->pe_rows, d);
   const int64_t r = rows < e->pe_rows ? rows : e->pe_rows;
   HIPC(hipMemcpyAsync(which == 0 ? e->pe_ar : e->pe_nar, data, (size_t)r * d * 4, hipMemcpyDefault, e->es));
   HIPC(hipStreamSynchronize(e->es));
@@ -481,7 +514,7 @@ static float* ada_vec(vx_engine* e, int stage, int site) {
 
 extern "C" int vx_finalize_weights(vx_engine* e) {
   if (!e) return fail(VX_ERR_ARG, "null engine");
-  HIPC(hipSetDevice(e->cfg.device));
+  ON_DEVICE(e->cfg.device);
   for (auto& k : e->keys)
     if (!e->w[k].set) return fail(VX_ERR_WEIGHTS, "missing key '%s' (strict load)", k.c_str());
   const vx_config& c = e->cfg;
@@ -789,7 +822,7 @@ static int prefill_impl(vx_engine* e, int slot, const int64_t* text, int32_t S, 
   if (S > c.max_text || A + 1 > c.max_audio) return fail(VX_ERR_CAPACITY, "S=%d / P=%d exceed capacity", S, P);
   if (A == 0) return fail(VX_ERR_ARG, "empty audio prefix needs prepend_bos");
   if (slot >= e->bmax) return fail(VX_ERR_ARG, "slot %d >= max_batch %d", slot, e->bmax);
-  HIPC(hipSetDevice(c.device));
+  ON_DEVICE(c.device);
   VXC(sync_in(e, stream));
   HIPC(hipEventRecord(e->ev_t[0], e->es));
   HIPC(hipMemcpyAsync(e->ids_text, text, (size_t)S * 8, hipMemcpyDefault, e->es));
@@ -885,7 +918,7 @@ extern "C" int vx_batch_prefill_all(vx_engine* e, int32_t n, const int64_t* cons
     rows += (size_t)((len[b] + 63) / 64) * 64;
     if (len[b] > maxlen) maxlen = len[b];
   }
-  HIPC(hipSetDevice(c.device));
+  ON_DEVICE(c.device);
   VXC(ensure_rows(e, rows, e->cap_audio, e->cap_text));
   VXC(sync_in(e, stream));
   HIPC(hipEventRecord(e->ev_t[0], e->es));
@@ -926,6 +959,7 @@ extern "C" int vx_batch_prefill_all(vx_engine* e, int32_t n, const int64_t* cons
   hgm.st = e->bst; hgm.B = n;
   hgm.A = e->bh; hgm.W = W<bf16>(e, "ar_predict_layer.weight"); hgm.N = AR_VOCAB; hgm.K = d; hgm.kgroups = 1;
   hgm.logits = e->blogits; hgm.logits_stride = LOGITS_CUR;
+  hgm.trace = e->btrace; hgm.trace_rows = e->btok_stride;
   VXC(launch_bgemm<BE_LOGITS>(hgm, e->es));
   HIPC(hipGetLastError());
   HIPC(hipEventRecord(e->ev_t[1], e->es));
@@ -1056,12 +1090,20 @@ extern "C" int vx_ar_decode(vx_engine* e, const vx_decode_params* p, void* strea
   if (!e->prefilled || e->decoded) return fail(VX_ERR_STATE, "vx_ar_decode needs a fresh vx_ar_prefill");
   if (!(p->temperature > 0.f)) return fail(VX_ERR_ARG, "temperature must be > 0");
   const vx_config& c = e->cfg;
-  HIPC(hipSetDevice(c.device));
+  ON_DEVICE(c.device);
   // upper bound on appended tokens (valle.py:1047: stops once bos + n_gen > 16 S)
   long long max_tok = 16LL * e->S + 1 - e->bos;
   if (p->forced) max_tok = p->n_forced;
   else if (p->max_new_tokens >= 0 && p->max_new_tokens < max_tok) max_tok = p->max_new_tokens;
-  if (e->bos + e->P + max_tok > c.max_audio) return fail(VX_ERR_CAPACITY, "need %lld audio rows, capacity %d", e->bos + e->P + max_tok, c.max_audio);
+  // 16 S + 1 is the WORST case (valle.py:1047); a trained model stops at EOS long before it, so a long text must not be
+  // refused up front: the launch bound is clamped to the rows the cache has, and only a decode that really fills them while
+  // the stop rule has not fired is a capacity error
+  const long long room = (long long)c.max_audio - e->bos - e->P;  // >= 1 (checked at prefill)
+  bool cap_limited = false;
+  if (max_tok > room) {
+    if (p->forced) return fail(VX_ERR_CAPACITY, "need %lld audio rows, capacity %d", e->bos + e->P + max_tok, c.max_audio);
+    max_tok = room; cap_limited = true;
+  }
   VXC(sync_in(e, stream));
   if (p->exp_noise) {
     if (p->noise_rows <= 0) return fail(VX_ERR_ARG, "noise_rows must be > 0");
@@ -1082,7 +1124,7 @@ extern "C" int vx_ar_decode(vx_engine* e, const vx_decode_params* p, void* strea
     HIPC(hipMemcpyAsync(e->d_forced, p->forced, (size_t)p->n_forced * 8, hipMemcpyDefault, e->es));
   }
   ArState& st = e->h_st[0];
-  st.top_k = p->top_k; st.temperature = p->temperature; st.max_new = p->max_new_tokens;
+  st.top_k = p->top_k; st.temperature = p->temperature; st.max_new = cap_limited ? (int)room : p->max_new_tokens;
   st.exp_noise = p->exp_noise ? e->d_noise : nullptr;
   st.noise_rows = p->noise_rows; st.seed = p->seed;
   st.forced = p->forced ? (p->n_forced > 0 ? e->d_forced : (const long long*)e->d_tokens) : nullptr;
@@ -1146,6 +1188,9 @@ extern "C" int vx_ar_decode(vx_engine* e, const vx_decode_params* p, void* strea
   e->n_pass = e->h_st[1].pass + 1;
   e->decoded = true;
   VXC(sync_out(e, stream));
+  if (cap_limited && e->stop_reason == VX_STOP_MAX_NEW)
+    return fail(VX_ERR_CAPACITY, "capacity exceeded: the KV cache filled (max_audio = %d rows: %d prompt + %d generated) before the stop rule fired; "
+                "raise max_audio", c.max_audio, e->bos + e->P, e->n_gen);
   return VX_OK;
 }
 
@@ -1153,7 +1198,7 @@ extern "C" int vx_ar_result(vx_engine* e, int64_t* tokens, int32_t capacity, int
                             int32_t* n_pass) {
   if (!e) return fail(VX_ERR_ARG, "null engine");
   if (!e->decoded) return fail(VX_ERR_STATE, "no finished decode");
-  HIPC(hipSetDevice(e->cfg.device));
+  ON_DEVICE(e->cfg.device);
   if (n_tokens) *n_tokens = e->n_gen;
   if (stop_reason) *stop_reason = e->stop_reason;
   if (n_pass) *n_pass = e->n_pass;
@@ -1237,6 +1282,7 @@ static int enqueue_batch_step(vx_engine* e, int B, hipStream_t s) {
   hgm.st = e->bst; hgm.B = B;
   hgm.A = e->bh; hgm.W = W<bf16>(e, "ar_predict_layer.weight"); hgm.N = AR_VOCAB; hgm.K = d; hgm.kgroups = 1;
   hgm.logits = e->blogits; hgm.logits_stride = LOGITS_CUR;
+  hgm.trace = e->btrace; hgm.trace_rows = e->btok_stride;
   VXC(launch_bgemm<BE_LOGITS>(hgm, s));
   return VX_OK;
 }
@@ -1245,8 +1291,9 @@ extern "C" int vx_batch_decode(vx_engine* e, int32_t B, const vx_decode_params* 
   if (!e || !params) return fail(VX_ERR_ARG, "null argument");
   if (B < 1 || B > e->bmax) return fail(VX_ERR_ARG, "n_slots %d outside [1, max_batch=%d]", B, e->bmax);
   const vx_config& c = e->cfg;
-  HIPC(hipSetDevice(c.device));
+  ON_DEVICE(c.device);
   long long bound = 1;
+  bool cap_limited[BMAX] = {};
   for (int b = 0; b < B; ++b) {
     const vx_decode_params& p = params[b];
     if (p.struct_size != (int32_t)sizeof(vx_decode_params)) return fail(VX_ERR_ARG, "vx_decode_params.struct_size mismatch");
@@ -1255,11 +1302,16 @@ extern "C" int vx_batch_decode(vx_engine* e, int32_t B, const vx_decode_params* 
     long long max_tok = 16LL * e->bS[b] + 1 - e->bbos[b];
     if (p.forced) max_tok = p.n_forced;
     else if (p.max_new_tokens >= 0 && p.max_new_tokens < max_tok) max_tok = p.max_new_tokens;
-    if (e->bbos[b] + e->bP[b] + max_tok > c.max_audio) return fail(VX_ERR_CAPACITY, "slot %d needs %lld audio rows, capacity %d", b, e->bbos[b] + e->bP[b] + max_tok, c.max_audio);
+    const long long room = (long long)c.max_audio - e->bbos[b] - e->bP[b];  // as in vx_ar_decode: clamp, fail only if it fills
+    cap_limited[b] = false;
+    if (max_tok > room) {
+      if (p.forced) return fail(VX_ERR_CAPACITY, "slot %d needs %lld audio rows, capacity %d", b, e->bbos[b] + e->bP[b] + max_tok, c.max_audio);
+      max_tok = room; cap_limited[b] = true;
+    }
     const long long steps = max_tok + (p.forced ? 1 : 0);
     if (steps > bound) bound = steps;
     ArState& st = e->h_bst[b];
-    st.top_k = p.top_k; st.temperature = p.temperature; st.max_new = p.max_new_tokens;
+    st.top_k = p.top_k; st.temperature = p.temperature; st.max_new = cap_limited[b] ? (int)room : p.max_new_tokens;
     st.exp_noise = p.exp_noise; st.noise_rows = p.noise_rows; st.seed = p.seed;
     st.forced = p.forced ? (p.n_forced > 0 ? (const long long*)p.forced : (const long long*)e->btok) : nullptr;
     st.n_forced = p.forced ? p.n_forced : 0;
@@ -1332,6 +1384,9 @@ extern "C" int vx_batch_decode(vx_engine* e, int32_t B, const vx_decode_params* 
     e->bprefilled[b] = false;
   }
   VXC(sync_out(e, stream));
+  for (int b = 0; b < B; ++b)
+    if (cap_limited[b] && e->breason[b] == VX_STOP_MAX_NEW)
+      return fail(VX_ERR_CAPACITY, "capacity exceeded in slot %d: the KV cache filled (max_audio = %d rows) before the stop rule fired; raise max_audio", b, c.max_audio);
   return VX_OK;
 }
 
@@ -1339,7 +1394,7 @@ extern "C" int vx_batch_result(vx_engine* e, int32_t slot, int64_t* tokens, int3
                                int32_t* stop_reason) {
   if (!e) return fail(VX_ERR_ARG, "null engine");
   if (slot < 0 || slot >= e->bmax) return fail(VX_ERR_ARG, "bad slot");
-  HIPC(hipSetDevice(e->cfg.device));
+  ON_DEVICE(e->cfg.device);
   const int n = e->bngen[slot];
   if (n_tokens) *n_tokens = n;
   if (stop_reason) *stop_reason = e->breason[slot];
@@ -1353,15 +1408,19 @@ extern "C" int vx_batch_result(vx_engine* e, int32_t slot, int64_t* tokens, int3
 }
 
 // ------------------------------------------------------------------------------ NAR
+// forced (optional, (T, Q)): stage i's argmax is still what codes_out reports, but the embedding that feeds stage i+1 is
+// taken from forced[:, i+1] - the input the reference itself gave that stage when `forced` are its codes (valle.py:1133-1134).
+// stage_logits (optional, (Q-1, T, 1024) fp32, host or device): every stage's logits rows (valle.py:1128).
 static int nar_impl(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
-                    const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream, bool pos_before_prenet) {
+                    const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream, bool pos_before_prenet,
+                    const int64_t* forced = nullptr, float* stage_logits = nullptr) {
   if (!e || !text_nar || !ar_tokens || !codes_out || (P > 0 && !prompts)) return fail(VX_ERR_ARG, "null argument");
   if (!e->finalized) return fail(VX_ERR_STATE, "weights not finalized");
   const vx_config& c = e->cfg;
   const int Q = c.num_quantizers;
   if (S2 <= 0 || T <= 0 || P < 0) return fail(VX_ERR_ARG, "bad S2/P/T");
   if (S2 > c.max_text || P + T > c.max_audio) return fail(VX_ERR_CAPACITY, "S2=%d P+T=%d exceed capacity", S2, P + T);
-  HIPC(hipSetDevice(c.device));
+  ON_DEVICE(c.device);
   VXC(sync_in(e, stream));
   HIPC(hipEventRecord(e->ev_t[4], e->es));
   const int dn = c.nar_d_model, A = P + T, N = S2 + A;
@@ -1369,6 +1428,7 @@ static int nar_impl(vx_engine* e, const int64_t* text_nar, int32_t S2, const int
   if (P) HIPC(hipMemcpyAsync(e->ids_prompts, prompts, (size_t)P * Q * 8, hipMemcpyDefault, e->es));
   HIPC(hipMemcpyAsync(e->ids_samples, ar_tokens, (size_t)T * 8, hipMemcpyDefault, e->es));
   copy_col_kernel<<<(T + 255) / 256, 256, 0, e->es>>>(e->ids_samples, e->d_codes, T, Q, 0);
+  if (forced) HIPC(hipMemcpyAsync(e->d_fcodes, forced, (size_t)T * Q * 8, hipMemcpyDefault, e->es));
   if (Q > 1) {
     HIPC(hipMemcpyAsync(e->ids_text, text_nar, (size_t)S2 * 8, hipMemcpyDefault, e->es));
     auto emb = [&](int j) { return W<float>(e, "nar_audio_embeddings." + std::to_string(j) + ".word_embeddings.weight"); };
@@ -1411,6 +1471,8 @@ static int nar_impl(vx_engine* e, const int64_t* text_nar, int32_t S2, const int
       VXC(gemm_rows(e, e->Hn, W<void>(e, "nar_predict_layers." + std::to_string(i) + ".weight"), nullptr, e->nar_logits,
                     T, 1024, dn, GE_PLAIN, true));
       argmax_rows_kernel<<<(T + 3) / 4, 256, 0, e->es>>>(e->nar_logits, 1024, T, e->ids_samples, e->d_codes, Q, i + 1);
+      if (stage_logits) HIPC(hipMemcpyAsync(stage_logits + (size_t)i * T * 1024, e->nar_logits, (size_t)T * 1024 * 4, hipMemcpyDefault, e->es));
+      if (forced && i < Q - 2) pick_col_kernel<<<(T + 255) / 256, 256, 0, e->es>>>(e->d_fcodes, Q, i + 1, e->ids_samples, T);
       if (i < Q - 2) {  // valle.py:1104-1108 / 1133-1134
         if (c.prefix_mode == 0 && P)
           embed_accum_kernel<<<P, 256, 0, e->es>>>(e->ids_prompts, Q, i + 1, emb(i + 1), 1024, dn, e->yemb, P, 0);
@@ -1433,6 +1495,13 @@ static int nar_impl(vx_engine* e, const int64_t* text_nar, int32_t S2, const int
 extern "C" int vx_nar(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
                       const int64_t* ar_tokens, int32_t T, int64_t* codes_out, void* stream) {
   return nar_impl(e, text_nar, S2, prompts, P, ar_tokens, T, codes_out, stream, false);
+}
+
+extern "C" int vx_nar_ex(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
+                         const int64_t* ar_tokens, int32_t T, int64_t* codes_out, const int64_t* forced_codes,
+                         float* stage_logits, int32_t continual, void* stream) {
+  return nar_impl(e, text_nar, S2, prompts, P, ar_tokens, T, codes_out, stream, continual && e && e->cfg.prefix_mode == 0,
+                  forced_codes, stage_logits);
 }
 
 extern "C" int vx_nar_continual(vx_engine* e, const int64_t* text_nar, int32_t S2, const int64_t* prompts, int32_t P,
@@ -1478,15 +1547,16 @@ static int ensure_rows(vx_engine* e, size_t rows, size_t audio_rows, size_t text
   VXC(regrow((void**)&e->ids_prompts, audio_rows * 8 * 8));
   VXC(regrow((void**)&e->ids_samples, audio_rows * 8));
   VXC(regrow((void**)&e->d_codes, audio_rows * 8 * 8));
+  VXC(regrow((void**)&e->d_fcodes, audio_rows * 8 * 8));
   return VX_OK;
 }
 
 // The NAR stages of n utterances at once (valle.py:1063-1134 per utterance): rows of all utterances are
 // concatenated (each segment starts at a multiple of 64 rows), so the GEMMs run at M ~ n x 1k rows where the
 // MFMA kernels are efficient, and attention runs per segment in one launch.
-extern "C" int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_nar, const int32_t* S2,
-                            const int64_t* const* prompts, const int32_t* P, const int64_t* const* ar_tokens,
-                            const int32_t* T, int64_t* const* codes_out, void* stream) {
+static int nar_batch_impl(vx_engine* e, int32_t n, const int64_t* const* text_nar, const int32_t* S2,
+                          const int64_t* const* prompts, const int32_t* P, const int64_t* const* ar_tokens,
+                          const int32_t* T, int64_t* const* codes_out, const int64_t* const* forced, void* stream) {
   if (!e || !text_nar || !S2 || !prompts || !P || !ar_tokens || !T || !codes_out) return fail(VX_ERR_ARG, "null argument");
   if (!e->finalized) return fail(VX_ERR_STATE, "weights not finalized");
   const vx_config& c = e->cfg;
@@ -1494,13 +1564,17 @@ extern "C" int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_
   if (n < 1 || n > BMAX) return fail(VX_ERR_ARG, "n must be 1..%d", BMAX);
   if (!e->bf16 || !use_mfma(e) || Q < 2) return fail(VX_ERR_UNSUPPORTED, "vx_nar_batch needs bf16 MFMA rows and num_quantizers > 1");
   if (c.flags & VX_FLAG_PRENET) return fail(VX_ERR_UNSUPPORTED, "vx_nar_batch: prenet models run on the batch-1 path only");
-  HIPC(hipSetDevice(c.device));
+  ON_DEVICE(c.device);
   std::vector<int> start(n), len(n), aoff(n), toff(n), soff(n);
   size_t rows = 0, arows = 0, trows = 0, srows = 0;
   int maxlen = 0;
   for (int b = 0; b < n; ++b) {
-    if (S2[b] <= 0 || T[b] <= 0 || P[b] < 0 || !text_nar[b] || !ar_tokens[b] || !codes_out[b] || (P[b] > 0 && !prompts[b]))
+    if (S2[b] <= 0 || T[b] <= 0 || P[b] < 0 || !text_nar[b] || !ar_tokens[b] || !codes_out[b] || (P[b] > 0 && !prompts[b]) ||
+        (forced && !forced[b]))
       return fail(VX_ERR_ARG, "bad utterance %d", b);
+    // per-utterance limits: positions index the sine table (pe_rows rows) separately for text and audio
+    if (S2[b] > e->pe_rows || P[b] + T[b] > e->pe_rows)
+      return fail(VX_ERR_CAPACITY, "utterance %d: S2=%d / P+T=%d exceed the %d positions of the sine table", b, S2[b], P[b] + T[b], e->pe_rows);
     start[b] = (int)rows; len[b] = S2[b] + P[b] + T[b];
     aoff[b] = (int)arows; toff[b] = (int)trows; soff[b] = (int)srows;
     rows += (size_t)((len[b] + 63) / 64) * 64;
@@ -1524,6 +1598,7 @@ extern "C" int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_
     long long* ids = e->ids_samples + toff[b];
     if (P[b]) HIPC(hipMemcpyAsync(idp, prompts[b], (size_t)P[b] * Q * 8, hipMemcpyDefault, e->es));
     HIPC(hipMemcpyAsync(ids, ar_tokens[b], (size_t)T[b] * 8, hipMemcpyDefault, e->es));
+    if (forced) HIPC(hipMemcpyAsync(e->d_fcodes + (size_t)toff[b] * Q, forced[b], (size_t)T[b] * Q * 8, hipMemcpyDefault, e->es));
     HIPC(hipMemcpyAsync(e->ids_text + soff[b], text_nar[b], (size_t)S2[b] * 8, hipMemcpyDefault, e->es));
     copy_col_kernel<<<(T[b] + 255) / 256, 256, 0, e->es>>>(ids, e->d_codes + (size_t)toff[b] * Q, T[b], Q, 0);
     float* ye = e->yemb + (size_t)aoff[b] * dn;
@@ -1548,13 +1623,14 @@ extern "C" int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_
     if (rc != VX_OK) break;
     const bool post = c.flags & VX_FLAG_POST_NORM;
     const float* fw = post ? nullptr : ada_vec(e, i, 2 * c.nar_num_layers);
-    for (int b = 0; b < n; ++b) {  // final AdaLN (pre-norm only) on the generated rows, compacted to [sum T][dn]
+    for (int b = 0; b < n && rc == VX_OK; ++b) {  // final AdaLN (pre-norm only) on the generated rows, compacted to [sum T][dn]
       const float* xr = e->X + (size_t)(start[b] + S2[b] + P[b]) * dn;
       bf16* hr = (bf16*)e->Hn + (size_t)toff[b] * dn;
       rc = post ? cast_rows(e, xr, hr, (size_t)T[b] * dn)
                 : ln_rows(e, xr, W<float>(e, "nar_decoder.norm.norm.weight"), W<float>(e, "nar_decoder.norm.norm.bias"), fw,
                           fw + dn, hr, T[b], dn);
     }
+    if (rc != VX_OK) break;
     const int nseg_keep = e->nseg;
     e->nseg = 0;  // the predict GEMM below is a plain GEMM
     rc = gemm_rows(e, e->Hn, W<void>(e, "nar_predict_layers." + std::to_string(i) + ".weight"), nullptr, e->nar_logits,
@@ -1562,6 +1638,8 @@ extern "C" int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_
     e->nseg = nseg_keep;
     if (rc != VX_OK) break;
     argmax_rows_kernel<<<((int)trows + 3) / 4, 256, 0, e->es>>>(e->nar_logits, 1024, (int)trows, e->ids_samples, e->d_codes, Q, i + 1);
+    if (forced && i < Q - 2)  // teacher forcing: the next stage sees the caller's codes of this stage (all segments at once)
+      pick_col_kernel<<<((int)trows + 255) / 256, 256, 0, e->es>>>(e->d_fcodes, Q, i + 1, e->ids_samples, (int)trows);
     if (i < Q - 2)
       for (int b = 0; b < n; ++b) {
         float* ye = e->yemb + (size_t)aoff[b] * dn;
@@ -1585,6 +1663,17 @@ extern "C" int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_
   return VX_OK;
 }
 
+extern "C" int vx_nar_batch(vx_engine* e, int32_t n, const int64_t* const* text_nar, const int32_t* S2,
+                            const int64_t* const* prompts, const int32_t* P, const int64_t* const* ar_tokens,
+                            const int32_t* T, int64_t* const* codes_out, void* stream) {
+  return nar_batch_impl(e, n, text_nar, S2, prompts, P, ar_tokens, T, codes_out, nullptr, stream);
+}
+extern "C" int vx_nar_batch_ex(vx_engine* e, int32_t n, const int64_t* const* text_nar, const int32_t* S2,
+                               const int64_t* const* prompts, const int32_t* P, const int64_t* const* ar_tokens,
+                               const int32_t* T, int64_t* const* codes_out, const int64_t* const* forced_codes, void* stream) {
+  return nar_batch_impl(e, n, text_nar, S2, prompts, P, ar_tokens, T, codes_out, forced_codes, stream);
+}
+
 extern "C" int vx_get_timings(vx_engine* e, double* out, int32_t n) {
   if (!e || !out) return fail(VX_ERR_ARG, "null argument");
   const double v[7] = {e->t_prefill, e->t_decode, e->t_nar, (double)e->n_pass, e->n_launch, e->t_bdecode, e->n_blaunch};
@@ -1594,7 +1683,7 @@ extern "C" int vx_get_timings(vx_engine* e, double* out, int32_t n) {
 
 extern "C" int vx_read_buffer(vx_engine* e, const char* name, void* dst, int64_t off, int64_t nbytes) {
   if (!e || !name || !dst) return fail(VX_ERR_ARG, "null argument");
-  HIPC(hipSetDevice(e->cfg.device));
+  ON_DEVICE(e->cfg.device);
   HIPC(hipStreamSynchronize(e->es));
   const std::string n = name;
   const char* src = nullptr;
@@ -1609,6 +1698,7 @@ extern "C" int vx_read_buffer(vx_engine* e, const char* name, void* dst, int64_t
   else if (n == "nar_logits") { src = (const char*)e->nar_logits; size = (int64_t)e->last_T * 1024 * 4; }
   else if (n == "ar_x") { src = (const char*)e->ar_x; size = (int64_t)e->cfg.d_model * 4; }
   else if (n == "nar_x") { src = (const char*)e->X; size = (int64_t)e->last_N * e->cfg.nar_d_model * 4; }
+  else if (n == "batch_trace" && e->btrace) { src = (const char*)e->btrace; size = (int64_t)e->bmax * e->btok_stride * AR_VOCAB * 4; }
   else if (n == "batch_logits" && e->bmax > 1) { src = (const char*)e->blogits; size = (int64_t)BMAX * LOGITS_CUR * 4; }
   else if (n == "batch_argmax" && e->bmax > 1) { src = (const char*)e->bargm; size = (int64_t)BMAX * e->btok_stride * 4; }
   else if (n == "batch_sampled" && e->bmax > 1) { src = (const char*)e->bsamp; size = (int64_t)BMAX * e->btok_stride * 4; }
@@ -1728,200 +1818,6 @@ extern "C" int vx_op_sample(const float* logits, int32_t V, int32_t top_k, float
   return VX_OK;
 }
 
-// ------------------------------------------------------------------------------ measurement aid
-__global__ void noop_kernel(float* p) {
-  if (p != nullptr && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) p[0] = 0.f;
-}
-
-// Launch floor of this box: time of a dependent chain of n trivial kernels (grid x block), replayed
-// `iters` times as a hipGraph and launched eagerly.  out[0] = us per kernel (graph), out[1] = eager.
-extern "C" int vx_debug_launch_floor(int32_t n_kernels, int32_t grid, int32_t block, int32_t iters, double* out) {
-  if (!out || n_kernels <= 0 || iters <= 0) return fail(VX_ERR_ARG, "bad argument");
-  hipStream_t s;
-  HIPC(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-  hipEvent_t e0, e1;
-  HIPC(hipEventCreate(&e0));
-  HIPC(hipEventCreate(&e1));
-  hipGraph_t g;
-  hipGraphExec_t ge;
-  HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-  for (int i = 0; i < n_kernels; ++i) noop_kernel<<<grid, block, 0, s>>>(nullptr);
-  HIPC(hipStreamEndCapture(s, &g));
-  HIPC(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-  for (int i = 0; i < 3; ++i) HIPC(hipGraphLaunch(ge, s));
-  HIPC(hipStreamSynchronize(s));
-  float ms = 0.f;
-  HIPC(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) HIPC(hipGraphLaunch(ge, s));
-  HIPC(hipEventRecord(e1, s));
-  HIPC(hipStreamSynchronize(s));
-  HIPC(hipEventElapsedTime(&ms, e0, e1));
-  out[0] = (double)ms * 1e3 / ((double)iters * n_kernels);
-  HIPC(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i)
-    for (int k = 0; k < n_kernels; ++k) noop_kernel<<<grid, block, 0, s>>>(nullptr);
-  HIPC(hipEventRecord(e1, s));
-  HIPC(hipStreamSynchronize(s));
-  HIPC(hipEventElapsedTime(&ms, e0, e1));
-  out[1] = (double)ms * 1e3 / ((double)iters * n_kernels);
-  (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
-  return VX_OK;
-}
-
-
-// Persistent-step probe (persist_probe.hpp): a chain of `stages` dependent 1024-wide GEMV stages in one launch.
-// out[0] = us per launch, out[1] = us per stage, out[2] = max |y - host| over the final vector, out[3] = spin-timeout flag.
-template <int ROWS>
-static hipError_t launch_chain(int mode, int nwg, const ChainArgs& a, hipStream_t s) {
-  if (mode == CHAIN_BARRIER_ONLY) chain_kernel<ROWS, CHAIN_BARRIER_ONLY><<<nwg, 256, 0, s>>>(a);
-  else if (mode == CHAIN_FENCE) chain_kernel<ROWS, CHAIN_FENCE><<<nwg, 256, 0, s>>>(a);
-  else if (mode == CHAIN_GROUP8) chain_kernel<ROWS, CHAIN_GROUP8><<<nwg, 256, 0, s>>>(a);
-  else if (mode == CHAIN_XCD) chain_kernel<ROWS, CHAIN_XCD><<<nwg, 256, 0, s>>>(a);
-  else chain_kernel<ROWS, CHAIN_BYPASS><<<nwg, 256, 0, s>>>(a);
-  return hipGetLastError();
-}
-
-extern "C" int vx_debug_stage_chain(int32_t nwg, int32_t stages, int32_t rows, int32_t mode, int32_t iters, double* out) {
-  if (!out || nwg <= 0 || nwg > 1024 || stages <= 0 || stages > 256 || iters <= 0 || mode < 0 || mode > 4 || (mode == 4 && nwg % 8))
-    return fail(VX_ERR_ARG, "bad argument");
-  if (rows != 4 && rows != 12 && rows != 16) return fail(VX_ERR_ARG, "rows must be 4, 12 or 16");
-  if (nwg * rows < 1024) return fail(VX_ERR_ARG, "nwg*rows must cover the 1024-wide vector");
-  hipDeviceProp_t prop;
-  HIPC(hipGetDeviceProperties(&prop, 0));
-  if (nwg > 2 * prop.multiProcessorCount) return fail(VX_ERR_ARG, "nwg exceeds what is certainly co-resident");
-  const size_t slice = (size_t)rows * 1024, nW = (size_t)stages * nwg * slice;
-  const int nout = nwg * rows;
-  std::vector<uint16_t> hW(nW);
-  uint32_t st = 12345u;
-  for (size_t i = 0; i < nW; ++i) {  // uniform in +-sqrt(3)/32 -> unit gain per stage
-    st = st * 1664525u + 1013904223u;
-    float v = (((st >> 8) & 0xFFFF) / 65535.0f * 2.f - 1.f) * 0.0541f;
-    uint32_t u; memcpy(&u, &v, 4);
-    hW[i] = (uint16_t)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
-  }
-  std::vector<float> hx(2 * (size_t)nout, 0.f);
-  for (int i = 0; i < 1024; ++i) hx[i] = sinf(0.37f * i);
-  bf16* dW = nullptr; float* dx = nullptr; unsigned* dc = nullptr;
-  HIPC(hipMalloc(&dW, nW * 2));
-  HIPC(hipMalloc(&dx, hx.size() * 4));
-  const size_t ctr_bytes = 256 * (2 + (size_t)nwg / 8);
-  HIPC(hipMalloc(&dc, ctr_bytes));
-  HIPC(hipMemcpy(dW, hW.data(), nW * 2, hipMemcpyHostToDevice));
-  hipStream_t s;
-  HIPC(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-  hipEvent_t e0, e1;
-  HIPC(hipEventCreate(&e0));
-  HIPC(hipEventCreate(&e1));
-  ChainArgs a{dW, dx, dc, dc + 1, stages, rows, mode};  // group counters live at dc + 64 * (1 + group)
-  auto once = [&]() -> hipError_t {
-    hipError_t r = hipMemsetAsync(dc, 0, ctr_bytes, s);
-    if (r != hipSuccess) return r;
-    return rows == 4 ? launch_chain<4>(mode, nwg, a, s) : rows == 12 ? launch_chain<12>(mode, nwg, a, s) : launch_chain<16>(mode, nwg, a, s);
-  };
-  HIPC(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
-  HIPC(once());
-  HIPC(hipStreamSynchronize(s));
-  std::vector<float> got(hx.size());
-  unsigned flags[2] = {0, 0};
-  HIPC(hipMemcpy(got.data(), dx, hx.size() * 4, hipMemcpyDeviceToHost));
-  HIPC(hipMemcpy(flags, dc, 8, hipMemcpyDeviceToHost));
-  double maxerr = 0.0;
-  if (mode == 1 || mode == 2) {  // host chain: only the first 1024 outputs feed the next stage
-    std::vector<float> x(hx.begin(), hx.begin() + 1024), y(nout);
-    auto w = [&](size_t i) { uint32_t u = (uint32_t)hW[i] << 16; float f; memcpy(&f, &u, 4); return f; };
-    for (int sidx = 0; sidx < stages; ++sidx) {
-      const int need = sidx + 1 == stages ? nout : 1024;
-      for (int o = 0; o < need; ++o) {
-        const size_t base = ((size_t)sidx * nwg + o / rows) * slice + (size_t)(o % rows) * 1024;
-        double acc = 0.0;
-        for (int k = 0; k < 1024; ++k) acc += (double)w(base + k) * x[k];
-        y[o] = (float)acc;
-      }
-      for (int k = 0; k < 1024; ++k) x[k] = y[k];
-      if (sidx + 1 == stages)
-        for (int o = 0; o < nout; ++o) maxerr = fmax(maxerr, fabs((double)got[(size_t)(stages & 1) * nout + o] - y[o]));
-    }
-  }
-  float ms = 0.f;
-  if (!flags[1]) {
-    for (int i = 0; i < 2; ++i) HIPC(once());
-    HIPC(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) HIPC(once());
-    HIPC(hipEventRecord(e1, s));
-    HIPC(hipStreamSynchronize(s));
-    HIPC(hipEventElapsedTime(&ms, e0, e1));
-    HIPC(hipMemcpy(flags, dc, 8, hipMemcpyDeviceToHost));
-  }
-  out[0] = (double)ms * 1e3 / iters;
-  out[1] = out[0] / stages;
-  out[2] = maxerr;
-  out[3] = (double)flags[1];
-  (void)hipFree(dW); (void)hipFree(dx); (void)hipFree(dc);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
-  return VX_OK;
-}
-
-
-// L2 -> CU fill-rate probe (persist_probe.hpp): grid workgroups of `threads` lanes, `unroll` 16-byte loads in flight
-// per lane, all over one shared region of `region_bytes` (keep it below the 4 MB of an XCD's L2).
-// out[0] = GB/s over the whole chip, out[1] = bytes per clock per CU at the clock in out[2] (GHz, from wall_clock).
-extern "C" int vx_debug_l2_fill(int32_t grid, int32_t threads, int32_t unroll, int64_t region_bytes, int32_t iters, double* out) {
-  if (!out || grid <= 0 || grid > 4096 || threads <= 0 || threads > 256 || threads % 64 || iters <= 0 || region_bytes < 65536)
-    return fail(VX_ERR_ARG, "bad argument");
-  if (unroll != 1 && unroll != 2 && unroll != 4 && unroll != 8 && unroll != 16) return fail(VX_ERR_ARG, "unroll must be 1/2/4/8/16");
-  const size_t nvec = (size_t)region_bytes / 16;
-  uint4* buf = nullptr; unsigned* sink = nullptr;
-  HIPC(hipMalloc((void**)&buf, nvec * 16));
-  HIPC(hipMalloc((void**)&sink, 16));
-  HIPC(hipMemset(buf, 1, nvec * 16));
-  hipStream_t s;
-  HIPC(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-  hipEvent_t e0, e1;
-  HIPC(hipEventCreate(&e0));
-  HIPC(hipEventCreate(&e1));
-  auto launch = [&]() {
-    switch (unroll) {
-      case 1: l2_fill_kernel<1><<<grid, threads, 0, s>>>(buf, nvec, iters, sink); break;
-      case 2: l2_fill_kernel<2><<<grid, threads, 0, s>>>(buf, nvec, iters, sink); break;
-      case 4: l2_fill_kernel<4><<<grid, threads, 0, s>>>(buf, nvec, iters, sink); break;
-      case 8: l2_fill_kernel<8><<<grid, threads, 0, s>>>(buf, nvec, iters, sink); break;
-      default: l2_fill_kernel<16><<<grid, threads, 0, s>>>(buf, nvec, iters, sink); break;
-    }
-  };
-  launch();
-  HIPC(hipStreamSynchronize(s));
-  HIPC(hipEventRecord(e0, s));
-  launch();
-  HIPC(hipEventRecord(e1, s));
-  HIPC(hipStreamSynchronize(s));
-  HIPC(hipGetLastError());
-  float ms = 0.f;
-  HIPC(hipEventElapsedTime(&ms, e0, e1));
-  const double bytes = (double)grid * threads * 16.0 * unroll * iters;
-  hipDeviceProp_t prop;
-  HIPC(hipGetDeviceProperties(&prop, 0));
-  const double ghz = prop.clockRate * 1e-6;
-  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  const int busy = grid < cus ? grid : cus;
-  out[0] = bytes / (ms * 1e-3) / 1e9;
-  out[1] = bytes / (ms * 1e-3) / (ghz * 1e9) / busy;
-  out[2] = ghz;
-  (void)hipFree(buf); (void)hipFree(sink);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
-  return VX_OK;
-}
-
-
-// Phase stamps of the last stamped kernel launch (probe builds, common.hpp VX_STAMP): out[i] = 10 ns ticks.
-extern "C" int vx_debug_read_stamps(unsigned long long* out, int32_t n) {
-#ifdef VX_STAMPS
-  if (!out || n < 1 || n > 32) return fail(VX_ERR_ARG, "bad argument");
-  HIPC(hipDeviceSynchronize());
-  HIPC(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vx_stamps), (size_t)n * 8));
-  return VX_OK;
-#else
-  (void)out; (void)n;
-  return fail(VX_ERR_UNSUPPORTED, "library built without -DVX_STAMPS (python vall-e_amd/csrc/build.py --stamps)");
+#ifdef VX_PROBES
+#include "probe_entry.hpp"
 #endif
-}

@@ -403,6 +403,12 @@ __global__ void copy_col_kernel(const long long* __restrict__ src, long long* __
   if (r < rows) codes[(size_t)r * Q + col] = src[r];
 }
 
+// dst[r] = codes[r][col] of a (rows, Q) code matrix (teacher-forced NAR stages)
+__global__ void pick_col_kernel(const long long* __restrict__ codes, int Q, int col, long long* __restrict__ dst, int rows) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) dst[r] = min(max(codes[(size_t)r * Q + col], 0ll), 1023ll);
+}
+
 template <typename OT>
 __global__ void convert_kernel(const float* __restrict__ src, OT* __restrict__ dst, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -54,6 +54,8 @@ _SIGS = {
     "vx_ar_decode": (C.c_int, [C.c_void_p, C.POINTER(VxDecodeParams), C.c_void_p]),
     "vx_ar_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vx_nar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "vx_nar_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_int32, C.c_void_p]),
     "vx_nar_continual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "vx_batch_prefill": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "vx_batch_prefill_all": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
@@ -61,6 +63,7 @@ _SIGS = {
     "vx_batch_decode": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(VxDecodeParams), C.c_void_p]),
     "vx_batch_result": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vx_nar_batch": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 7 + [C.c_void_p]),
+    "vx_nar_batch_ex": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_void_p]),
     "vx_get_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32]),
     "vx_read_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int64]),
     "vx_op_layernorm": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p]),
@@ -69,10 +72,15 @@ _SIGS = {
     "vx_op_attention": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
     "vx_op_sample": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "vx_op_convert_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+# measurement probes (csrc/probes.h): exported by the probe builds only (`csrc/build.py --probes|--stamps`), never by libvallex.so
+_PROBE_SIGS = {
     "vx_debug_launch_floor": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "vx_debug_stage_chain": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_double)]),
     "vx_debug_l2_fill": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     "vx_debug_read_stamps": (C.c_int, [C.POINTER(C.c_uint64), C.c_int32]),
+    "vx_debug_kstamps": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
 }
 
 
@@ -93,8 +101,20 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in _PROBE_SIGS.items():  # present in the probe builds only
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
+
+
+def load_probe_library(stamps: bool = False) -> C.CDLL:
+    """Measurement scripts (tests/probes) only: makes the probe build the process's library.  Must be called before anything
+    else loads libvallex.so."""
+    assert _lib is None, "a library is already loaded in this process"
+    return load_library(os.path.join(_HERE, "csrc", "libvallex_stamps.so" if stamps else "libvallex_probes.so"))
 
 
 def _check(code: int):
@@ -209,17 +229,25 @@ class Engine:
         return toks, reason.value, npass.value
 
     def nar(self, text_nar: torch.Tensor, prompts: torch.Tensor, ar_tokens: torch.Tensor, out_device=None, stream=None,
-            continual: bool = False):
+            continual: bool = False, forced_codes: Optional[torch.Tensor] = None, stage_logits: bool = False):
         """prompts: (P, Q); returns codes (T, Q) int64 on ``out_device`` (default: prompts' device).  ``continual``:
-        the NAR body of VALLE.continual (vx_nar_continual)."""
+        the NAR body of VALLE.continual (vx_nar_continual).  Parity-test options (vx_nar_ex): ``forced_codes`` (T, Q) feeds
+        every stage the given codes of the earlier stages; ``stage_logits=True`` also returns the (Q-1, T, 1024) logits."""
         text_nar = text_nar.to(torch.int64).contiguous()
         prompts = prompts.to(torch.int64).contiguous()
         ar_tokens = ar_tokens.to(torch.int64).contiguous()
         T, Q = ar_tokens.numel(), self.cfg.num_quantizers
         out = torch.empty((T, Q), dtype=torch.int64, device=out_device if out_device is not None else prompts.device)
-        fn = self.lib.vx_nar_continual if continual else self.lib.vx_nar
-        _check(fn(self.h, _ptr(text_nar), text_nar.numel(), _ptr(prompts), prompts.shape[0], _ptr(ar_tokens), T, _ptr(out), stream))
-        return out
+        if forced_codes is None and not stage_logits:
+            fn = self.lib.vx_nar_continual if continual else self.lib.vx_nar
+            _check(fn(self.h, _ptr(text_nar), text_nar.numel(), _ptr(prompts), prompts.shape[0], _ptr(ar_tokens), T, _ptr(out), stream))
+            return out
+        fc = None if forced_codes is None else forced_codes.to(torch.int64).contiguous()
+        assert fc is None or tuple(fc.shape) == (T, Q)
+        lg = torch.empty((max(Q - 1, 0), T, 1024), dtype=torch.float32) if stage_logits else None
+        _check(self.lib.vx_nar_ex(self.h, _ptr(text_nar), text_nar.numel(), _ptr(prompts), prompts.shape[0], _ptr(ar_tokens), T,
+                                  _ptr(out), _ptr(fc), _ptr(lg), int(continual), stream))
+        return (out, lg) if stage_logits else out
 
     # -- batched decode (BASELINE configs[2]) -------------------------------------------------------
     def batch_prefill(self, slot: int, text: torch.Tensor, prompt_cb0: torch.Tensor, stream=None):
@@ -267,8 +295,9 @@ class Engine:
         _check(self.lib.vx_batch_result(self.h, slot, _ptr(toks), n.value, C.byref(n), C.byref(reason)))
         return toks, reason.value
 
-    def nar_batch(self, texts, prompts, tokens, out_device=None, stream=None):
-        """lists of per-utterance tensors (as for ``nar``) -> list of (T_i, Q) int64 code tensors."""
+    def nar_batch(self, texts, prompts, tokens, out_device=None, stream=None, forced_codes=None):
+        """lists of per-utterance tensors (as for ``nar``) -> list of (T_i, Q) int64 code tensors.  ``forced_codes``: optional
+        list of (T_i, Q) tensors, per-stage teacher forcing as in ``nar`` (vx_nar_batch_ex)."""
         n, Q = len(texts), self.cfg.num_quantizers
         texts = [t.to(torch.int64).contiguous() for t in texts]
         prompts = [p.to(torch.int64).contiguous() for p in prompts]
@@ -277,9 +306,13 @@ class Engine:
                 for t, p in zip(tokens, prompts)]
         ptrs = lambda ts: (C.c_void_p * n)(*[_ptr(t) for t in ts])
         ints = lambda vs: (C.c_int32 * n)(*vs)
-        _check(self.lib.vx_nar_batch(self.h, n, ptrs(texts), ints([t.numel() for t in texts]), ptrs(prompts),
-                                     ints([p.shape[0] for p in prompts]), ptrs(tokens), ints([t.numel() for t in tokens]),
-                                     ptrs(outs), stream))
+        fc = None
+        if forced_codes is not None:
+            forced_codes = [f.to(torch.int64).contiguous() for f in forced_codes]
+            fc = ptrs(forced_codes)
+        _check(self.lib.vx_nar_batch_ex(self.h, n, ptrs(texts), ints([t.numel() for t in texts]), ptrs(prompts),
+                                        ints([p.shape[0] for p in prompts]), ptrs(tokens), ints([t.numel() for t in tokens]),
+                                        ptrs(outs), fc, stream))
         return outs
 
     def timings(self):
@@ -346,7 +379,7 @@ def op_sample(logits, top_k, temperature, exp_noise):
     return out[0], out[1]
 
 
-def launch_floor(n_kernels=62, grid=256, block=256, iters=200):
+def launch_floor(n_kernels=62, grid=256, block=256, iters=200):  # the three probes below need load_probe_library()
     lib = load_library()
     out = (C.c_double * 2)()
     _check(lib.vx_debug_launch_floor(n_kernels, grid, block, iters, out))

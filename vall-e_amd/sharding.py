@@ -4,7 +4,13 @@ The hot path is batch-1 and utterances share no state (valle.py:989), so N GPUs 
 replicas.  The only exchange is at the edges: rank 0 scatters the padded id tensors
 (KB-scale) and gathers the code matrices back — ``torch.distributed`` scatter / gather, i.e.
 RCCL over xGMI with backend "nccl", gloo on CPU in the tests.  No collective touches the data
-path in between.  Utterance u = step * world + rank runs on ``rank``.
+path in between.
+
+Partition (``plan_partition``): a decode costs about 16 x S steps (the reference's stop rule,
+valle.py:1047), so rank 0 sorts the utterances by text length, cuts the sorted list into contiguous
+groups of ``group`` utterances (one padded batch each: neighbours in length, so the batch's step count
+is set by utterances of similar length) and deals the groups to the ranks in snake order
+(0..W-1, W-1..0, ...), which evens out the summed cost per rank.  The gather restores utterance order.
 """
 from __future__ import annotations
 
@@ -14,6 +20,21 @@ import torch
 import torch.distributed as dist
 
 Utt = Tuple[torch.Tensor, torch.Tensor, torch.Tensor]  # x (1,S) int64, x_lens (1,) int32, y (1,P,Q) int64
+
+
+def plan_partition(lengths: Sequence[int], world: int, group: int = 1) -> List[List[int]]:
+    """-> per rank, the utterance indices it decodes, ``group`` consecutive entries forming one batch.
+    ``len(lengths)`` must be a multiple of ``world * group`` (every rank gets the same number of groups)."""
+    n = len(lengths)
+    if n % (world * group):
+        raise ValueError(f"{n} utterances do not split into {world} ranks x groups of {group}")
+    order = sorted(range(n), key=lambda i: (-int(lengths[i]), i))
+    groups = [order[k : k + group] for k in range(0, n, group)]
+    per_rank: List[List[int]] = [[] for _ in range(world)]
+    for gi, g in enumerate(groups):
+        r = gi % (2 * world)
+        per_rank[r if r < world else 2 * world - 1 - r] += g
+    return per_rank
 
 
 def _pack(utts: Sequence[Utt], smax: int, pmax: int, q: int):
@@ -29,18 +50,18 @@ def _pack(utts: Sequence[Utt], smax: int, pmax: int, q: int):
     return text, prom, lens
 
 
-def scatter_utterances(all_utts: Optional[Sequence[Utt]], per_rank: int, device, world: int, rank: int) -> List[Utt]:
-    """rank 0 passes ``world * per_rank`` utterances ordered [step][rank]; every rank returns its own
-    ``per_rank`` utterances on ``device``."""
+def scatter_lists(per_rank_utts: Optional[Sequence[Sequence[Utt]]], per_rank: int, device, world: int, rank: int) -> List[Utt]:
+    """rank 0 passes one list of ``per_rank`` utterances for every rank; every rank returns its own on ``device``."""
     if world == 1:
-        assert all_utts is not None and len(all_utts) == per_rank
-        return [(x.to(device), xl.to(device), y.to(device)) for x, xl, y in all_utts]
+        assert per_rank_utts is not None and len(per_rank_utts) == 1 and len(per_rank_utts[0]) == per_rank
+        return [(x.to(device), xl.to(device), y.to(device)) for x, xl, y in per_rank_utts[0]]
     hdr = torch.zeros(3, dtype=torch.int64, device=device)
     if rank == 0:
-        assert all_utts is not None and len(all_utts) == world * per_rank
-        hdr[0] = max(u[0].shape[1] for u in all_utts)
-        hdr[1] = max(u[2].shape[1] for u in all_utts)
-        hdr[2] = all_utts[0][2].shape[2]
+        assert per_rank_utts is not None and len(per_rank_utts) == world and all(len(l) == per_rank for l in per_rank_utts)
+        flat = [u for l in per_rank_utts for u in l]
+        hdr[0] = max(u[0].shape[1] for u in flat)
+        hdr[1] = max(u[2].shape[1] for u in flat)
+        hdr[2] = flat[0][2].shape[2]
     dist.broadcast(hdr, src=0)
     smax, pmax, q = (int(v) for v in hdr)
     text = torch.empty((per_rank, smax), dtype=torch.int64, device=device)
@@ -48,7 +69,7 @@ def scatter_utterances(all_utts: Optional[Sequence[Utt]], per_rank: int, device,
     lens = torch.empty((per_rank, 2), dtype=torch.int64, device=device)
     lists = [None, None, None]
     if rank == 0:
-        packed = [_pack([all_utts[s * world + r] for s in range(per_rank)], smax, pmax, q) for r in range(world)]
+        packed = [_pack(l, smax, pmax, q) for l in per_rank_utts]
         lists = [[p[i].to(device) for p in packed] for i in range(3)]
     for buf, lst in zip((text, prom, lens), lists):
         dist.scatter(buf, scatter_list=lst, src=0)
@@ -60,11 +81,11 @@ def scatter_utterances(all_utts: Optional[Sequence[Utt]], per_rank: int, device,
     return out
 
 
-def gather_codes(codes: Sequence[torch.Tensor], device, world: int, rank: int) -> Optional[List[torch.Tensor]]:
-    """Every rank passes its ``(1, T_i, Q)`` code tensors; rank 0 gets all of them back in utterance
-    order (u = step * world + rank), other ranks get None."""
+def gather_lists(codes: Sequence[torch.Tensor], device, world: int, rank: int) -> Optional[List[List[torch.Tensor]]]:
+    """Every rank passes its ``(1, T_i, Q)`` code tensors (the same count on every rank); rank 0 gets one list per
+    rank back, other ranks get None."""
     if world == 1:
-        return list(codes)
+        return [list(codes)]
     n = len(codes)
     q = codes[0].shape[2] if n else 0
     meta = torch.tensor([max([c.shape[1] for c in codes], default=0), q], dtype=torch.int64, device=device)
@@ -81,18 +102,52 @@ def gather_codes(codes: Sequence[torch.Tensor], device, world: int, rank: int) -
     dist.gather(lens, gather_list=got_l, dst=0)
     if rank != 0:
         return None
-    out = []
-    for s in range(n):
-        for r in range(world):
-            out.append(got[r][s : s + 1, : int(got_l[r][s])])
-    return out
+    return [[got[r][s : s + 1, : int(got_l[r][s])] for s in range(n)] for r in range(world)]
+
+
+def scatter_utterances(all_utts: Optional[Sequence[Utt]], per_rank: int, device, world: int, rank: int) -> List[Utt]:
+    """Fixed dealing, no sort: rank 0 passes ``world * per_rank`` utterances ordered [step][rank] (utterance
+    u = step * world + rank runs on ``rank``)."""
+    lists = None
+    if rank == 0:
+        assert all_utts is not None and len(all_utts) == world * per_rank
+        lists = [[all_utts[s * world + r] for s in range(per_rank)] for r in range(world)]
+    return scatter_lists(lists, per_rank, device, world, rank)
+
+
+def gather_codes(codes: Sequence[torch.Tensor], device, world: int, rank: int) -> Optional[List[torch.Tensor]]:
+    """Inverse of ``scatter_utterances``: rank 0 gets all code tensors back in utterance order u = step * world + rank."""
+    got = gather_lists(codes, device, world, rank)
+    if got is None:
+        return None
+    return [got[r][s] for s in range(len(codes)) for r in range(world)]
 
 
 def infer_sharded(run_one, all_utts: Optional[Sequence[Utt]], per_rank: int, device, world: int, rank: int,
-                  run_many=None):
-    """scatter -> decode the local utterances -> gather.  ``run_one(x, x_lens, y) -> (1,T,Q)`` decodes them one
-    at a time (batch-1, the reference's mode); ``run_many(list_of_utts) -> list of (1,T,Q)`` decodes them as one
-    padded batch (``VALLE.inference_batch``, BASELINE configs[3]: 256 utterances = 32 per GPU on 8 GPUs)."""
-    mine = scatter_utterances(all_utts, per_rank, device, world, rank)
-    outs = run_many(mine) if run_many is not None else [run_one(*u) for u in mine]
-    return gather_codes(outs, device, world, rank)
+                  run_many=None, group: int = 1):
+    """scatter -> decode the local utterances -> gather; rank 0 returns the codes in the order of ``all_utts``.
+    ``run_one(x, x_lens, y) -> (1,T,Q)`` decodes one utterance at a time (batch-1, the reference's mode);
+    ``run_many(list_of_utts) -> list of (1,T,Q)`` decodes ``group`` of them as one padded batch
+    (``VALLE.inference_batch``, BASELINE configs[3]: 256 utterances = 32 per GPU on 8 GPUs).  ``per_rank`` must be a
+    multiple of ``group``.  The partition is ``plan_partition`` over the text lengths."""
+    plan = None
+    lists = None
+    if rank == 0:
+        assert all_utts is not None and len(all_utts) == world * per_rank
+        plan = plan_partition([u[0].shape[1] for u in all_utts], world, group)
+        lists = [[all_utts[i] for i in idx] for idx in plan]
+    mine = scatter_lists(lists, per_rank, device, world, rank)
+    if run_many is not None:
+        outs = []
+        for k in range(0, len(mine), group):
+            outs += list(run_many(mine[k : k + group]))
+    else:
+        outs = [run_one(*u) for u in mine]
+    got = gather_lists(outs, device, world, rank)
+    if got is None:
+        return None
+    res: List[Optional[torch.Tensor]] = [None] * (world * per_rank)
+    for r, idx in enumerate(plan):
+        for j, i in enumerate(idx):
+            res[i] = got[r][j]
+    return res
