@@ -76,10 +76,11 @@ def cpu_model_name() -> str:
     return "unknown"
 
 
-def cpu_baseline(sd, cfg, x, x_lens, y, n_tokens: int, n_tokens_1t: int):
+def cpu_baseline(sd, cfg, x, x_lens, y, budget_s: float):
     """The reference algorithm (no KV cache, fp32, oracle/valle_oracle.inference_faithful — a checked port, kind="port") on a
     bounded sample of the same workload, timed on this box's host cores: once on all the cores this process may use and once
-    on ONE thread (what the reference's CLI does: torch.set_num_threads(1), valle/bin/infer.py:262-263)."""
+    on ONE thread (what the reference's CLI does: torch.set_num_threads(1), valle/bin/infer.py:262-263).  The sample (number of
+    AR steps in front of the 7 NAR stages) is sized from one calibration pass so that each leg takes about `budget_s`."""
     import torch
     from oracle import valle_oracle as vo  # checker / baseline only — never the product path
 
@@ -87,28 +88,38 @@ def cpu_baseline(sd, cfg, x, x_lens, y, n_tokens: int, n_tokens_1t: int):
                        cfg.num_quantizers)
     ctx0 = S_TEXT + P_PROMPT
 
-    def run(threads, n):
-        torch.set_num_threads(threads)
+    def run(n, skip_nar=False):
         t0 = time.time()
-        codes = vo.inference_faithful(m, x, x_lens, y, None, TOP_K, TEMP, exp_noise=torch.ones(n + 2, 1025), max_new_tokens=n)
-        dt = time.time() - t0
-        return codes.shape[1] / dt, dt
+        codes = vo.inference_faithful(m, x, x_lens, y, None, TOP_K, TEMP, exp_noise=torch.ones(n + 2, 1025), max_new_tokens=n,
+                                      skip_nar=skip_nar)
+        return codes.shape[1], time.time() - t0
+
+    def leg(threads):
+        torch.set_num_threads(threads)
+        _, t1 = run(1, skip_nar=True)          # two forward passes over ~273 rows: the calibration
+        per_pass = t1 / 2.0
+        # n AR tokens cost n + 1 passes, the 7 NAR stages about 7 x 1.4 passes (the NAR stack has 1.4 x the AR stack's parameters)
+        n = int(max(1, min(16, budget_s / per_pass - 11)))
+        print(f"bench.py: cpu baseline on {threads} thread(s): {per_pass:.2f} s per pass, sampling {n} AR steps + NAR", file=sys.stderr, flush=True)
+        frames, dt = run(n)
+        return frames / dt, dt, n
 
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # a one-GPU box's CPU share is 16 cores; more threads than that only oversubscribe its quota
     before = torch.get_num_threads()
-    v_all, dt_all = run(cores, n_tokens)
-    v_one, dt_one = run(1, n_tokens_1t)
+    v_all, dt_all, n_all = leg(cores)
+    v_one, dt_one, n_one = leg(1)
     torch.set_num_threads(before)
     tail = "fp32, no KV cache; later AR steps cost more (O(T^2)), so the full-length CPU rate is lower than this"
     return {
         "value": round(v_all, 3), "unit": "codec-tokens/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
-        "sample": f"first {n_tokens} of 753 AR steps (ctx {ctx0}..{ctx0 + n_tokens}) + 7 NAR stages over {ctx0 + n_tokens} rows, "
+        "sample": f"first {n_all} of 753 AR steps (ctx {ctx0}..{ctx0 + n_all}) + 7 NAR stages over {ctx0 + n_all} rows, "
                   f"{dt_all:.1f} s wall on {cores} threads; {tail}",
         "one_thread": {"value": round(v_one, 3), "unit": "codec-tokens/s", "cores": 1,
-                       "sample": f"first {n_tokens_1t} AR steps + 7 NAR stages over {ctx0 + n_tokens_1t} rows, {dt_one:.1f} s wall, "
+                       "sample": f"first {n_one} AR steps + 7 NAR stages over {ctx0 + n_one} rows, {dt_one:.1f} s wall, "
                                  "torch.set_num_threads(1) as valle/bin/infer.py:262-263 does"},
     }
 
@@ -120,8 +131,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="bf16", help="bf16 | fp32 (the token-exact parity mode) | fp8nar (bf16 AR, fp8 NAR GEMMs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=16)
-    ap.add_argument("--cpu-tokens-1t", type=int, default=2)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per leg of the cpu_baseline sample")
     ap.add_argument("--batch", type=int, default=1, help="utterances decoded together per GPU per step (1 = the headline "
                     "batch-1 workload, BASELINE configs[1]; 32 = configs[2], with --gpus 8 configs[3]; 64 + --precision fp8nar + "
                     "--text-len 94 = configs[4])")
@@ -345,7 +355,7 @@ def run_rank(args) -> int:
                                                      "quoted at this run's mean context; NOT measured in this run")
         if world == 1 and not args.no_cpu_baseline and not dry:
             x, x_lens, y = synthetic_inputs(S_TEXT, P_PROMPT, 8, seed=1)
-            out["cpu_baseline"] = cpu_baseline(sd, cfg, x, x_lens, y, args.cpu_tokens, args.cpu_tokens_1t)
+            out["cpu_baseline"] = cpu_baseline(sd, cfg, x, x_lens, y, args.cpu_budget)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

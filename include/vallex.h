@@ -42,7 +42,11 @@ enum vx_status {
 
 enum vx_precision {
   VX_PREC_F32 = 0, /* fp32 weights, KV cache and activations: the token-exact parity mode */
-  VX_PREC_BF16 = 1 /* bf16 matrices / KV cache / GEMM operands, fp32 residual stream + accumulate */
+  VX_PREC_BF16 = 1, /* bf16 matrices / KV cache / GEMM operands, fp32 residual stream + accumulate */
+  VX_PREC_FP8_NAR = 2 /* VX_PREC_BF16, and the NAR stages' QKV / FFN1 / FFN2 GEMMs (valle.py:1115-1134 through
+                         transformer.py:296-334) on OCP e4m3 operands with E8M0 scales per 32 k (MXFP8, the matrix cores'
+                         block-scaled fp8 form) wherever the stage runs at >= 4096 concatenated rows (vx_nar_batch);
+                         attention, out-projection, predict layers and the whole AR path stay bf16 (BASELINE configs[4]) */
 };
 
 enum vx_stop_reason {
@@ -198,6 +202,15 @@ int vx_op_gemv(int32_t prec, const void* W, const float* bias, const float* x, f
                int32_t relu, void* stream);
 int vx_op_gemm(int32_t prec, int32_t use_mfma, const void* A, const void* W, const float* bias, float* C_f32,
                int32_t M, int32_t N, int32_t K, int32_t relu, void* stream);
+/* The MXFP8 (VX_PREC_FP8_NAR) kernels on caller data.  vx_op_gemm_mx: A (M, K) / W (N, K) fp32 device pointers are quantised
+ * on the device as the engine does (e4m3 + one E8M0 scale per 32 k) and multiplied on the block-scaled matrix cores; out_mode 0:
+ * c_out = C (M, N) fp32 (+bias, ReLU); out_mode 2 (FFN1's form): c_out = ReLU(C + bias) as e4m3 bytes (M, N), sc_out = its block
+ * scales (N/32, ld), ld = M rounded up to 256.  qa_out / sa_out (optional): the quantised A and its scales (K/32, ld).
+ * vx_op_layernorm_mx: LayerNorm / AdaLN with the quantised result, q_out (rows, d) bytes + s_out (d/32, ld) scales. */
+int vx_op_gemm_mx(const float* A, const float* W, const float* bias, void* c_out, void* sc_out, int32_t M, int32_t N, int32_t K,
+                  int32_t relu, int32_t out_mode, void* qa_out, void* sa_out, void* stream);
+int vx_op_layernorm_mx(const float* x, const float* gamma, const float* beta, const float* ada_w, const float* ada_b, void* q_out,
+                       void* s_out, int32_t rows, int32_t d, void* stream);
 int vx_op_attention(int32_t prec, int32_t use_mfma, const void* qkv, void* out, int32_t rows, int32_t nhead,
                     int32_t hd, int32_t text_len_for_ar_mask /* <0: no mask */, void* stream);
 int vx_op_sample(const float* logits, int32_t V, int32_t top_k, float temperature, const float* exp_noise,

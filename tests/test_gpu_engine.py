@@ -278,30 +278,30 @@ def test_eos_at_first_pass_raises_syntax_error_like_the_reference():
 
 def test_eos_by_argmax():
     """valle.py:1045: the loop stops when argmax(logits) == EOS, whatever the sample is.  The EOS row of the predict layer is
-    crafted from the oracle's own final hidden state of pass k (logit_EOS(j) = alpha h_k . h_j), so that EOS is the argmax at
-    pass k and at no earlier pass, while the noise makes the multinomial draw token 3 at every pass (sample != EOS): only the
-    argmax branch can stop the decode.  Engine == oracle, stop reason VX_STOP_EOS_ARGMAX."""
+    crafted from the oracle's own final hidden states: alpha x (the part of h_k orthogonal to h_0 .. h_{k-1}), so the EOS logit is
+    ~0 at every earlier pass and top + 1 at pass k, while the noise makes the multinomial draw a chosen non-EOS token at every
+    pass: only the argmax branch can stop the decode.  Engine == oracle, stop reason VX_STOP_EOS_ARGMAX."""
     from valle_amd.weights import synthetic_inputs
 
     cfg, sd, m = _tiny()
     x, xl, y = synthetic_inputs(5, 8)
     noise = torch.ones(16 * 5 + 2, 1025)
-    noise[:, 3] = 1e-9  # p[3] / q[3] dwarfs every other ratio: token 3 is sampled at every pass
+    toks = [(37 * p + 11) % 1000 for p in range(noise.shape[0])]
+    for p, t in enumerate(toks):
+        noise[p, t] = 1e-9  # p[t] / q[t] dwarfs every other ratio: token t is what pass p samples
     vo, om = _oracle(cfg, sd)
     tr = {}
     full = vo.inference_cached(om, x, xl, y, None, -100, 1.0, noise, trace=tr, skip_nar=True)
-    assert full.shape[1] == 81 and bool((full[0, :, 0] == 3).all())
-    H = torch.stack(tr["ar_hidden"])                 # (passes, d): independent of the predict layer
+    assert full[0, :, 0].tolist() == toks[:81]
+    H = torch.stack(tr["ar_hidden"])                        # (passes, d): independent of the predict layer
     top = torch.stack(tr["ar_logits"])[:, :1024].max(1)[0]  # best non-EOS logit of every pass
-    k = alpha = None
-    for cand in range(4, 30):
-        a = float(top[cand] + 1.0) / float(H[cand] @ H[cand])
-        eos = a * (H[: cand + 1] @ H[cand])
-        if bool((eos[:cand] < top[:cand] - 0.5).all()) and float(eos[cand]) > float(top[cand]) + 0.5:
-            k, alpha = cand, a
-            break
-    assert k is not None, "no pass found whose hidden state separates from the earlier ones"
-    sd["ar_predict_layer.weight"][1024] = alpha * H[k]
+    k = 6
+    B = H[:k]
+    v = H[k] - B.t() @ torch.linalg.lstsq(B.t(), H[k].unsqueeze(1)).solution[:, 0]
+    alpha = float(top[k] + 1.0) / float(v @ H[k])
+    eos = alpha * (H[: k + 1] @ v)
+    assert bool((eos[:k] < top[:k] - 0.5).all()) and float(eos[k]) > float(top[k]) + 0.5
+    sd["ar_predict_layer.weight"][1024] = alpha * v
     vo, om = _oracle(cfg, sd)
     want = vo.inference_cached(om, x, xl, y, None, -100, 1.0, noise)
     assert want.shape == (1, k, 8)  # passes 0..k-1 appended a token, pass k stopped by argmax
@@ -313,7 +313,7 @@ def test_eos_by_argmax():
     assert e.ar_result()[1] == 1  # VX_STOP_EOS_ARGMAX
     n_pass = k + 1
     assert int(e.read("ar_argmax", (n_pass,), dtype=torch.int32)[k]) == 1024
-    assert int(e.read("ar_sampled", (n_pass,), dtype=torch.int32)[k]) == 3  # the sample was NOT EOS
+    assert int(e.read("ar_sampled", (n_pass,), dtype=torch.int32)[k]) == toks[k]  # the sample was NOT EOS
 
 
 def test_long_text_is_not_refused_by_the_worst_case_bound():

@@ -142,3 +142,61 @@ def test_sampling_single_wave_variant_large_vocab(eng, top_k):
         want = int(vo.topk_sampling(logits.clone(), top_k, 0.9, q))
         got, am = eng.op_sample(logits[0].cuda(), top_k, 0.9, q[0].cuda())
         assert am == int(torch.argmax(logits, -1)) and got == want
+
+
+# ---- MXFP8 kernels of VX_PREC_FP8_NAR (mx_kernels.hpp) against the host emulation of the same quantiser (tests/mx_ref.py) ----
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 1024), (4100, 3072, 1024), (513, 1024, 4096)])
+def test_mx_gemm_matches_host_emulation(eng, M, N, K):
+    """Quantiser: bit-exact bytes and scales.  GEMM: both operands dequantise to exact fp32 values and every product of two of them
+    is exact in fp32, so the matrix core's result differs from an fp64 evaluation only by fp32 accumulation: tolerance 1e-5 of the
+    row's magnitude budget sum |a||w|."""
+    from mx_ref import mx_dequant, mx_gemm_ref, mx_quant
+
+    A, W, b = _rand(M, K, seed=1, scale=1.7), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
+    A[3, 5] = 300.0  # an outlier block and an all-zero block
+    A[min(7, M - 1), 32:64] = 0.0
+    ld = (M + 255) // 256 * 256
+    C, qa, sa = eng.op_gemm_mx(A.cuda(), W.cuda(), b.cuda(), return_quant=True)
+    q_ref, s_ref = mx_quant(A)
+    assert torch.equal(qa.cpu(), q_ref)
+    assert torch.equal(sa.cpu()[:, :M].t().contiguous(), s_ref)
+    assert int(sa.cpu()[:, M:].max()) == 0 if ld > M else True
+    ref = mx_gemm_ref(A, W) + b
+    budget = mx_dequant(*mx_quant(A)).abs().double() @ mx_dequant(*mx_quant(W)).abs().double().t()
+    assert bool(((C.cpu() - ref).abs().double() <= 1e-5 * budget + 1e-6).all())
+    Cr = eng.op_gemm_mx(A.cuda(), W.cuda(), b.cuda(), relu=True).cpu()
+    assert bool(((Cr - ref.clamp_min(0)).abs().double() <= 1e-5 * budget + 1e-6).all())
+    # the quantisation error itself, for the record: relative to the fp32 product
+    exact = F.linear(A.double(), W.double(), b.double()).float()
+    print(M, N, K, "mxfp8 vs fp32 GEMM: rel. error %.4f of the output rms" % float((ref - exact).pow(2).mean().sqrt() / exact.pow(2).mean().sqrt()))
+
+
+def test_mx_gemm_quantised_output(eng):
+    """FFN1's epilogue: ReLU(C + bias) leaves the GEMM as e4m3 bytes with one scale per 32 columns (the A operand of FFN2)."""
+    from mx_ref import mx_dequant, mx_gemm_ref, mx_quant
+
+    M, N, K = 700, 1024, 256
+    A, W, b = _rand(M, K, seed=4), _rand(N, K, seed=5, scale=K ** -0.5), _rand(N, seed=6)
+    (c8, sc) = eng.op_gemm_mx(A.cuda(), W.cuda(), b.cuda(), out_mx=True)
+    got = mx_dequant(c8.cpu(), sc.cpu()[:, :M].t().contiguous())
+    ref = (mx_gemm_ref(A, W) + b).clamp_min(0)
+    # the kernel quantises ITS fp32 sums (accumulation order differs from the host's by ~1e-6): a value on a rounding boundary
+    # may land one e4m3 step away, so compare dequantised values within one step (2^-3 relative) and require most to be equal
+    want = mx_dequant(*mx_quant(ref))
+    assert bool(((got - want).abs() <= 0.13 * want.abs() + 1e-6).all())
+    assert float((got == want).float().mean()) >= 0.999
+
+
+@pytest.mark.parametrize("rows,d", [(300, 1024), (37, 256)])
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_layernorm_mx(eng, rows, d, adaptive):
+    from mx_ref import mx_dequant, mx_quant
+
+    x, g, b = _rand(rows, d, seed=1, scale=3.0), 1 + 0.1 * _rand(d, seed=2), 0.1 * _rand(d, seed=3)
+    w, c = (1 + 0.1 * _rand(d, seed=4), 0.1 * _rand(d, seed=5)) if adaptive else (None, None)
+    dev = lambda t: None if t is None else t.cuda()
+    f32 = eng.op_layernorm(dev(x), dev(g), dev(b), dev(w), dev(c), torch.float32).cpu()  # same arithmetic, unquantised
+    q, sc = eng.op_layernorm_mx(dev(x), dev(g), dev(b), dev(w), dev(c))
+    q_ref, s_ref = mx_quant(f32)
+    assert torch.equal(sc.cpu()[:, :rows].t().contiguous(), s_ref)
+    assert torch.equal(q.cpu(), q_ref)

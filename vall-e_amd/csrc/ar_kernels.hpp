@@ -49,6 +49,7 @@ struct GemvArgs {
   // are never used.
   const void* pf;
   unsigned pf_slice, pf_total;
+  int kid;  // position in the decode step (probe builds: VX_KSTAMP; -1 = not stamped)
 };
 
 // y = W x (+epilogue).  One wave owns RPW rows at a time; a row is KCH 16-byte loads per lane;
@@ -62,6 +63,7 @@ template <typename WT, int KCH, int RPW, int PRO, int NPF = 0>
 __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ W_, const float* __restrict__ xin,
                                                    const float* __restrict__ gamma_, const float* __restrict__ beta_,
                                                    unsigned nk, const GemvArgs a) {
+  VX_KSTAMP_BEGIN();
   constexpr int VEC = Vec16<WT>::N;
   constexpr int V4 = VEC / 4;
   __shared__ __attribute__((aligned(16))) float xs[PRO == PRO_ATTN ? 1024 : 4];
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ W_, 
 #pragma unroll
     for (int i = 0; i < NPF; ++i) asm volatile("" ::"v"(pfv[i].x), "v"(pfv[i].y), "v"(pfv[i].z), "v"(pfv[i].w));
   }
+  VX_KSTAMP_END(a.kid, st_pass);
 }
 
 // ---- single-query attention over the KV cache, split over keys (flash-decoding) -----------
@@ -306,7 +309,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ W_, 
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ q, const T* __restrict__ kc,
                                                           const T* __restrict__ vc, float* __restrict__ part,
-                                                          const ArState* __restrict__ st, int ctx_max, float scale) {
+                                                          const ArState* __restrict__ st, int ctx_max, float scale,
+                                                          int kid) {
+  VX_KSTAMP_BEGIN();
   constexpr int VEC = Vec16<T>::N;
   constexpr int LPK = HD / VEC;        // lanes per key: 8 (bf16) / 16 (fp32)
   constexpr int KPW = 64 / LPK;        // keys per wave-load
@@ -392,6 +397,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     if (tid == 0) { p[0] = M; p[1] = l; }
     p[4 + tid] = o;
   }
+#ifdef VX_STAMPS
+  VX_KSTAMP_END(kid, st->pass);
+#endif
 }
 
 // ---- the same split-KV partials for head sizes other than 64 (4 .. 32: the reference's own tests run head_dim 4,
@@ -400,7 +408,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_decode_small_kernel(const float* __restrict__ q, const T* __restrict__ kc,
                                                                 const T* __restrict__ vc, float* __restrict__ part,
-                                                                const ArState* __restrict__ st, int ctx_max, float scale) {
+                                                                const ArState* __restrict__ st, int ctx_max, float scale,
+                                                                int kid) {
   __shared__ float sm_m[256], sm_l[256];
   __shared__ float sm_o[256][HD + 1];
   const int h = blockIdx.x / ATT_NSPLIT, s = blockIdx.x - h * ATT_NSPLIT;
@@ -458,6 +467,7 @@ struct SampleArgs {
   int d;
   // batched decode: workgroup = slot; per-slot strides (0 in the batch-1 step, grid = 1)
   int logits_stride, tok_stride;
+  int kid;  // probe builds: VX_KSTAMP id (-1 = not stamped)
 };
 
 __device__ __forceinline__ uint32_t order_key(float v) {
@@ -673,6 +683,7 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
 // block-level reductions, while wave 0 alone also holds all keys (NV0 per lane) for the exact top-k select.
 template <int NVT, int NV0>
 __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) {
+  VX_KSTAMP_BEGIN();
   __shared__ float s_av[4], s_sv[4], s_f[4];
   __shared__ int s_ai[4], s_si[4];
   __shared__ uint32_t cand_lds[64];
@@ -813,6 +824,7 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
     o.z = __fadd_rn(ev.z, __fmul_rn(alpha, pv.z)); o.w = __fadd_rn(ev.w, __fmul_rn(alpha, pv.w));
     *reinterpret_cast<float4*>(xout + c) = o;
   }
+  VX_KSTAMP_END(a.kid, pass + 1);  // the pass index every later kernel of this step reads
 }
 
 }  // namespace vx

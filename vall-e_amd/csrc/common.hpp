@@ -12,8 +12,26 @@ extern __device__ unsigned long long g_vx_stamps[32];
   do {                                                                                                     \
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_vx_stamps[i] = wall_clock64(); \
   } while (0)
+// Per-kernel stamps of the AR decode step INSIDE the hipGraph replay (probe builds): every wave of a stamped kernel records
+// s_memrealtime (100 MHz) when it starts and when it has issued its last instruction, into ring slot `pass & 15` of the buffer
+// vx_debug_kstamps owns: [16 passes][64 kernels][1024 wave slots][entry, exit].  The host reduces entry = min / exit = max
+// over the waves of a kernel (tests/probes/ar_step_stamps.py).  The entry value is read at the top but only stored at the end,
+// so that the stamp adds no memory instruction in front of the kernel's own first loads.
+extern __device__ unsigned long long* g_vx_kstamps;
+#define VX_KSTAMP_BEGIN() const unsigned long long vx_t0_ = __builtin_amdgcn_s_memrealtime()
+#define VX_KSTAMP_END(kid, pass)                                                                                      \
+  do {                                                                                                                \
+    if (g_vx_kstamps != nullptr && (kid) >= 0 && (kid) < 64 && (threadIdx.x & 63) == 0) {                             \
+      const unsigned long long vx_t1_ = __builtin_amdgcn_s_memrealtime();                                             \
+      const int vx_slot_ = min((int)blockIdx.x, 255) * 4 + min((int)(threadIdx.x >> 6), 3);                           \
+      unsigned long long* vx_p_ = g_vx_kstamps + ((((size_t)((pass) & 15) * 64 + (kid)) * 1024 + vx_slot_) * 2);      \
+      vx_p_[0] = vx_t0_; vx_p_[1] = vx_t1_;                                                                            \
+    }                                                                                                                 \
+  } while (0)
 #else
 #define VX_STAMP(i) do { } while (0)
+#define VX_KSTAMP_BEGIN() do { } while (0)
+#define VX_KSTAMP_END(kid, pass) do { } while (0)
 #endif
 
 namespace vx {

@@ -15,11 +15,13 @@
 #include "../../include/vallex.h"
 #ifdef VX_STAMPS
 __device__ unsigned long long g_vx_stamps[32];
+__device__ unsigned long long* g_vx_kstamps = nullptr;
 #endif
 #include "ar_kernels.hpp"
 #include "rows_kernels.hpp"
 #include "mfma_kernels.hpp"
 #include "batch_kernels.hpp"
+#include "mx_kernels.hpp"
 
 using namespace vx;
 
@@ -70,9 +72,13 @@ struct Tensor {
   size_t numel = 0;
   bool low = false;  // stored in the precision's matrix type (bf16 in VX_PREC_BF16)
   bool set = false;
+  // VX_PREC_FP8_NAR: MXFP8 copy of the NAR stack's in_proj / linear1 / linear2 (mx_kernels.hpp): e4m3 bytes (N, K) and E8M0
+  // block scales (K/32, N); the bf16 copy stays (row counts below the 256-tile path run on it)
+  uint8_t *q8 = nullptr, *s8 = nullptr;
 };
 
 struct LayerW {
+  const uint8_t *in_q8 = nullptr, *in_s8 = nullptr, *w1_q8 = nullptr, *w1_s8 = nullptr, *w2_q8 = nullptr, *w2_s8 = nullptr;
   const void *in_w, *out_w, *w1, *w2;
   const float *in_b, *out_b, *b1, *b2;
   const float *n1_g, *n1_b, *n2_g, *n2_b;
@@ -83,6 +89,9 @@ constexpr int POLL_CHUNK = 32;
 struct vx_engine {
   vx_config cfg{};
   bool bf16 = false;
+  bool fp8nar = false;  // VX_PREC_FP8_NAR: bf16 everywhere + MXFP8 QKV / FFN GEMMs in the NAR stages at >= 4096 rows
+  uint8_t *Hn8 = nullptr, *SHn = nullptr, *FF8 = nullptr, *SFF = nullptr;  // MXFP8 row operands and their scales (ld = mx_ld)
+  int mx_ld = 0;
   bool hd64 = true;  // head_dim 64 in both stacks: the MFMA row kernels and the batched decode apply
   size_t esz = 4;  // bytes per matrix / KV / GEMM-operand element
   int num_cu = 256;
@@ -179,6 +188,11 @@ static bool is_matrix_key(const std::string& k) {
   if (k.find("project_layer") != std::string::npos) return false;
   return ends("in_proj_weight") || ends("out_proj.weight") || ends("linear1.weight") || ends("linear2.weight") ||
          k.rfind("ar_predict_layer", 0) == 0 || k.rfind("nar_predict_layers", 0) == 0;
+}
+
+static bool is_mx_key(const std::string& k) {  // the NAR stack's QKV / FFN matrices (BASELINE configs[4])
+  auto ends = [&](const char* s) { size_t n = strlen(s); return k.size() >= n && k.compare(k.size() - n, n, s) == 0; };
+  return k.rfind("nar_decoder.layers.", 0) == 0 && (ends("in_proj_weight") || ends("linear1.weight") || ends("linear2.weight"));
 }
 
 // The reference's state_dict layout (valle.py:85-259); mirrored by valle_amd/weights.py.
@@ -286,11 +300,14 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
     return fail(VX_ERR_UNSUPPORTED, "d_model must be a multiple of 64 at head_dim 64");
   if (!hd64 && c.max_batch > 1) return fail(VX_ERR_UNSUPPORTED, "batched decode needs head_dim 64");
   if (c.max_text <= 0 || c.max_audio <= 0) return fail(VX_ERR_ARG, "capacities must be positive");
-  if (c.precision != VX_PREC_F32 && c.precision != VX_PREC_BF16) return fail(VX_ERR_ARG, "bad precision");
+  if (c.precision != VX_PREC_F32 && c.precision != VX_PREC_BF16 && c.precision != VX_PREC_FP8_NAR) return fail(VX_ERR_ARG, "bad precision");
+  if (c.precision == VX_PREC_FP8_NAR && (c.num_quantizers < 2 || c.nar_d_model % 256 || c.nar_d_model / c.nar_nhead != 64 ||
+                                         (c.flags & (VX_FLAG_POST_NORM | VX_FLAG_PRENET | VX_FLAG_SIMPLE_ROWS))))
+    return fail(VX_ERR_UNSUPPORTED, "VX_PREC_FP8_NAR needs a pre-norm NAR stack without prenets, head_dim 64 and nar_d_model % 256 == 0");
   if ((c.flags & (VX_FLAG_POST_NORM | VX_FLAG_PRENET)) && c.max_batch > 1)
     return fail(VX_ERR_UNSUPPORTED, "post-norm / prenet models run on the batch-1 path only");
   if (c.max_batch < 0 || c.max_batch > BMAX) return fail(VX_ERR_ARG, "max_batch must be 0..%d", BMAX);
-  if (c.max_batch > 1 && (c.precision != VX_PREC_BF16 || c.d_model % 128))
+  if (c.max_batch > 1 && (c.precision == VX_PREC_F32 || c.d_model % 128))
     return fail(VX_ERR_UNSUPPORTED, "batched decode needs bf16 precision and d_model % 128 == 0");
 
   ON_DEVICE(c.device);
@@ -310,7 +327,8 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
 static int create_body(vx_engine* e) {
   const vx_config& c = e->cfg;
   const bool hd64 = c.d_model / c.nhead == 64 && (c.num_quantizers == 1 || c.nar_d_model / c.nar_nhead == 64);
-  e->bf16 = c.precision == VX_PREC_BF16;
+  e->bf16 = c.precision != VX_PREC_F32;
+  e->fp8nar = c.precision == VX_PREC_FP8_NAR;
   e->hd64 = hd64;
   e->esz = e->bf16 ? 2 : 4;
   hipDeviceProp_t prop;
@@ -368,6 +386,15 @@ static int create_body(vx_engine* e) {
   VXC(dalloc_t(e, &e->d_codes, (size_t)c.max_audio * 8));
   VXC(dalloc_t(e, &e->d_fcodes, (size_t)c.max_audio * 8));
   e->cap_audio = c.max_audio; e->cap_text = c.max_text;
+  if (e->fp8nar) {
+    e->mx_ld = (e->n_max + 255) / 256 * 256;
+    VXC(dalloc_t(e, &e->Hn8, n * dmax));
+    VXC(dalloc_t(e, &e->FF8, n * 4 * dmax));
+    VXC(dalloc_t(e, &e->SHn, (size_t)(dmax / 32) * e->mx_ld));
+    VXC(dalloc_t(e, &e->SFF, (size_t)(4 * dmax / 32) * e->mx_ld));
+    HIPC(hipMemsetAsync(e->SHn, 0, (size_t)(dmax / 32) * e->mx_ld, e->es));  // the pad rows' scales must stay finite
+    HIPC(hipMemsetAsync(e->SFF, 0, (size_t)(4 * dmax / 32) * e->mx_ld, e->es));
+  }
   if (e->bf16 && !(c.flags & VX_FLAG_SIMPLE_ROWS)) {
     e->slab_rows = e->n_max < 4095 ? e->n_max : 4095;
     VXC(dalloc_t(e, &e->slab, (size_t)4 * e->slab_rows * dmax));
@@ -425,6 +452,10 @@ static int create_body(vx_engine* e) {
   for (auto& k : e->keys) {
     Tensor& t = e->w[k];
     VXC(dalloc(e, &t.p, t.numel * (t.low ? 2 : 4)));
+    if (e->fp8nar && is_mx_key(k)) {
+      VXC(dalloc_t(e, &t.q8, t.numel));
+      VXC(dalloc_t(e, &t.s8, t.numel / 32));
+    }
   }
   HIPC(hipStreamSynchronize(e->es));  // the fills above are done before the caller's uploads (other streams) begin
   return VX_OK;
@@ -467,6 +498,10 @@ extern "C" int vx_set_weight(vx_engine* e, const char* key, const float* data, c
     HIPC(hipMalloc((void**)&stage, t.numel * 4));
     HIPC(hipMemcpyAsync(stage, data, t.numel * 4, hipMemcpyDefault, e->es));
     convert_kernel<bf16><<<1024, 256, 0, e->es>>>(stage, (bf16*)t.p, t.numel);
+    if (t.q8 != nullptr) {  // (N, K) -> e4m3 bytes + (K/32, N) block scales, from the fp32 values
+      const int N = (int)t.shape[0], K = (int)t.shape[1];
+      mx_quant_rows_kernel<<<(N + 3) / 4, 256, 0, e->es>>>(stage, t.q8, t.s8, N, K, N);
+    }
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(e->es));
     HIPC(hipFree(stage));
@@ -500,6 +535,8 @@ static void fill_layers(vx_engine* e, const std::string& pre, int L, bool adapti
     l.out_w = W<void>(e, p + ".self_attn.out_proj.weight"); l.out_b = W<float>(e, p + ".self_attn.out_proj.bias");
     l.w1 = W<void>(e, p + ".linear1.weight"); l.b1 = W<float>(e, p + ".linear1.bias");
     l.w2 = W<void>(e, p + ".linear2.weight"); l.b2 = W<float>(e, p + ".linear2.bias");
+    { const Tensor &a = e->w.at(p + ".self_attn.in_proj_weight"), &b = e->w.at(p + ".linear1.weight"), &c2 = e->w.at(p + ".linear2.weight");
+      l.in_q8 = a.q8; l.in_s8 = a.s8; l.w1_q8 = b.q8; l.w1_s8 = b.s8; l.w2_q8 = c2.q8; l.w2_s8 = c2.s8; }
     const std::string s = adaptive ? ".norm" : "";
     l.n1_g = W<float>(e, p + ".norm1" + s + ".weight"); l.n1_b = W<float>(e, p + ".norm1" + s + ".bias");
     l.n2_g = W<float>(e, p + ".norm2" + s + ".weight"); l.n2_b = W<float>(e, p + ".norm2" + s + ".bias");
@@ -722,6 +759,8 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
   // split over 2-4 workgroups per tile, every slice writes an fp32 slab, and the LayerNorm that follows the GEMM anyway
   // adds bias + slabs to x in a fixed order.  Larger M (batched rows) has enough tiles and adds in the GEMM epilogue.
   const bool splitk = use_mfma(e) && M < 4096 && M <= e->slab_rows && d % 128 == 0 && d >= 128;
+  // VX_PREC_FP8_NAR: the NAR stages' QKV / FFN GEMMs on MXFP8 once the row count reaches the 256-tile path (batched NAR)
+  const bool mx = e->fp8nar && ada_stage >= 0 && M >= 4096 && !post && use_mfma(e) && d % 256 == 0;
   const size_t sstride = (size_t)M * d;
   const int sp_d = split_for(d), sp_ff = split_for(4 * d);
   Fold pend;  // FFN2 slabs of the previous layer, folded by the next norm (pre-norm) or by the trailing fold pass
@@ -734,9 +773,16 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
     }
     // pre-norm (transformer.py:296-302): Hn = norm1(x).  post-norm (303-308): the block reads x itself; Hn already
     // holds it in operand precision from the previous layer's norm2 (layer 0: cast here)
+    if (mx) {  // MXFP8 QKV: the LayerNorm quantises its own row, the GEMM writes bf16 q/k/v (+ V^T) for the bf16 attention
+      layernorm_rows_mx_kernel<4><<<(M + 3) / 4, 256, 0, e->es>>>(e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn8, e->SHn, M, d, e->mx_ld);
+      if (mx_gemm_dispatch(e->Hn8, e->SHn, e->mx_ld, l.in_q8, l.in_s8, 3 * d, l.in_b, e->QKV, nullptr, 0, M, 3 * d, d, GE_BIAS,
+                           MX_OUT_BF16, e->es, (bf16*)e->VT, 2 * d, e->vt_ld))
+        return fail(VX_ERR_UNSUPPORTED, "mx gemm: shape %d x %d x %d", M, 3 * d, d);
+    } else {
     if (!post) { VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d, nullptr, pend)); pend = Fold(); }
     else if (li == 0) VXC(cast_rows(e, e->X, e->Hn, (size_t)M * d));
     VXC(gemm_rows(e, e->Hn, l.in_w, l.in_b, e->QKV, M, 3 * d, d, GE_BIAS, false, use_mfma(e)));
+    }
     if (fill_cache && e->nseg > 0) {  // batched prefill: segment z -> slot z
       const size_t kvl = (size_t)2 * H * e->ctx_max * 64;  // elements per layer
       kv_scatter_seg_kernel<bf16><<<dim3(e->max_seg_len, e->nseg), 256, 0, e->es>>>(
@@ -754,6 +800,14 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
       fo.part = e->slab; fo.nsplit = sp_d; fo.stride = sstride; fo.bias = l.out_b;
     } else {
       VXC(gemm_rows(e, e->ATT, l.out_w, l.out_b, e->X, M, d, d, GE_RESID, true));
+    }
+    if (mx) {  // MXFP8 FFN: LN2 -> fp8, FFN1's epilogue quantises its ReLU output per 32-wide block, FFN2 adds into x
+      layernorm_rows_mx_kernel<4><<<(M + 3) / 4, 256, 0, e->es>>>(e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn8, e->SHn, M, d, e->mx_ld);
+      if (mx_gemm_dispatch(e->Hn8, e->SHn, e->mx_ld, l.w1_q8, l.w1_s8, 4 * d, l.b1, e->FF8, e->SFF, e->mx_ld, M, 4 * d, d, GE_RELU,
+                           MX_OUT_MX, e->es) ||
+          mx_gemm_dispatch(e->FF8, e->SFF, e->mx_ld, l.w2_q8, l.w2_s8, d, l.b2, e->X, nullptr, 0, M, d, 4 * d, GE_RESID, MX_OUT_F32, e->es))
+        return fail(VX_ERR_UNSUPPORTED, "mx gemm: FFN shapes at M=%d d=%d", M, d);
+      continue;
     }
     if (!post) VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn, M, d, nullptr, fo));
     else VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d, e->X, fo));  // x = norm1(x + sa(x))
@@ -807,6 +861,7 @@ static int enqueue_head(vx_engine* e, hipStream_t s, const float* x = nullptr, f
   a.N = AR_VOCAB; a.K = c.d_model;
   a.pro = (post && prefilled) ? PRO_COPY : PRO_LN; a.epi = EPI_LOGITS;
   a.st = st ? st : e->d_st;
+  a.kid = (!prefilled && st == nullptr) ? 61 : -1;  // the decode step's head (probe builds)
   if (pfW) gemv_prefetch(a, pfW, pfN, pfK, e->bf16, e->num_cu);  // decode step: the next token's first GEMVs
   return launch_gemv(e->bf16, a, e->num_cu, s);
 }
@@ -990,10 +1045,12 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
   sa.pe = e->pe_ar; sa.x = e->ar_x; sa.d = d;
   const bool prenet = c.flags & VX_FLAG_PRENET;
   if (prenet) { sa.alpha = e->d_zero; sa.x = e->ar_e; }  // raw embedding; the position is added after the prenet
+  sa.kid = 0;  // stamp ids of the step (probe builds): 0 sampling, 1 + 5 l + {0 QKV, 1 attention, 2 out-proj, 3 FFN1, 4 FFN2}, 61 head
   sample_embed4_kernel<5, 17><<<1, 256, 0, s>>>(sa);
   if (prenet) {  // y_emb = ar_audio_prenet(E[tok]); x = y_emb + alpha * pe (valle.py:1013-1015): three fp32 GEMVs
     GemvArgs p0{}, p1{}, p2{};
     p0.st = p1.st = p2.st = e->d_st;
+    p0.kid = p1.kid = p2.kid = -1;
     p0.W = W<void>(e, "ar_audio_prenet.0.weight"); p0.bias = W<float>(e, "ar_audio_prenet.0.bias");
     p0.x = e->ar_e; p0.y = e->ar_h1; p0.N = PRENET_H; p0.K = d; p0.pro = PRO_COPY; p0.epi = EPI_RELU;
     p1.W = W<void>(e, "ar_audio_prenet.3.weight"); p1.bias = W<float>(e, "ar_audio_prenet.3.bias");
@@ -1040,15 +1097,16 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
       else { a.gamma = e->ar_l[li - 1].n2_g; a.beta = e->ar_l[li - 1].n2_b; a.xnorm_out = e->ar_xn; res = e->ar_xn; }
     }
     warm(a, 4 * li);
+    a.kid = 1 + 5 * li;
     VXC(launch_gemv(e->bf16, a, e->num_cu, s));
 #define AD(HDV)                                                                                                                                              \
   if (hd == HDV) {                                                                                                                                           \
-    if (e->bf16) attn_decode_small_kernel<bf16, HDV><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale); \
-    else attn_decode_small_kernel<float, HDV><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale);      \
+    if (e->bf16) attn_decode_small_kernel<bf16, HDV><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale, 2 + 5 * li); \
+    else attn_decode_small_kernel<float, HDV><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale, 2 + 5 * li);      \
   }
     if (hd == 64) {
-      if (e->bf16) attn_decode_kernel<bf16, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale);
-      else attn_decode_kernel<float, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale);
+      if (e->bf16) attn_decode_kernel<bf16, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale, 2 + 5 * li);
+      else attn_decode_kernel<float, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale, 2 + 5 * li);
     }
     AD(32) AD(16) AD(8) AD(4)
 #undef AD
@@ -1058,6 +1116,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     o.W = l.out_w; o.bias = l.out_b; o.part = e->ar_part; o.y = e->ar_x; o.N = d; o.K = d; o.pro = PRO_ATTN; o.epi = EPI_RESID;
     o.res = res;
     warm(o, 4 * li + 1);
+    o.kid = 3 + 5 * li;
     VXC(launch_gemv(e->bf16, o, e->num_cu, s));
     // f = relu(linear1(LN2(x)))
     GemvArgs f{};
@@ -1066,6 +1125,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     f.N = 4 * d; f.K = d; f.pro = PRO_LN; f.epi = EPI_RELU;
     if (post) { f.gamma = l.n1_g; f.beta = l.n1_b; f.xnorm_out = e->ar_xn; }  // x = norm1(x + sa(x)), kept in ar_xn
     warm(f, 4 * li + 2);
+    f.kid = 4 + 5 * li;
     VXC(launch_gemv(e->bf16, f, e->num_cu, s));
     // x += linear2(f)
     GemvArgs g{};
@@ -1073,6 +1133,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     g.W = l.w2; g.bias = l.b2; g.x = e->ar_f; g.y = e->ar_x; g.N = d; g.K = 4 * d; g.pro = PRO_COPY; g.epi = EPI_RESID;
     if (post) g.res = e->ar_xn;  // raw sum norm1(..) + ff(..); its norm2 runs in the next layer's (or the head's) prologue
     warm(g, 4 * li + 3);
+    g.kid = 5 + 5 * li;
     VXC(launch_gemv(e->bf16, g, e->num_cu, s));
   }
   if (pf_dist > 0) {
@@ -1537,6 +1598,15 @@ static int ensure_rows(vx_engine* e, size_t rows, size_t audio_rows, size_t text
   VXC(regrow(&e->VT, dmax * (size_t)e->vt_ld * 2));
   HIPC(hipMemsetAsync(e->VT, 0, dmax * (size_t)e->vt_ld * 2, e->es));
   HIPC(hipMemsetAsync(e->X, 0, rows * dmax * 4, e->es));
+  if (e->fp8nar) {
+    e->mx_ld = (int)((rows + 255) / 256 * 256);
+    VXC(regrow((void**)&e->Hn8, rows * dmax));
+    VXC(regrow((void**)&e->FF8, rows * 4 * dmax));
+    VXC(regrow((void**)&e->SHn, (dmax / 32) * (size_t)e->mx_ld));
+    VXC(regrow((void**)&e->SFF, (4 * dmax / 32) * (size_t)e->mx_ld));
+    HIPC(hipMemsetAsync(e->SHn, 0, (dmax / 32) * (size_t)e->mx_ld, e->es));
+    HIPC(hipMemsetAsync(e->SFF, 0, (4 * dmax / 32) * (size_t)e->mx_ld, e->es));
+  }
   if (e->slab != nullptr) {  // keep the split-K path available for concatenated rows below the 256^2 threshold
     e->slab_rows = rows < 4095 ? (int)rows : 4095;
     VXC(regrow((void**)&e->slab, (size_t)4 * e->slab_rows * dmax * 4));
@@ -1753,6 +1823,52 @@ extern "C" int vx_op_gemm(int32_t prec, int32_t mfma, const void* A, const void*
     if (mfma) return fail(VX_ERR_UNSUPPORTED, "MFMA GEMM is bf16 only");
     VXC(gemm_rows_t<float>(false, (const float*)A, (const float*)Wp, bias, C, M, N, K, epi, true, s));
   }
+  HIPC(hipGetLastError());
+  return VX_OK;
+}
+
+// MXFP8 GEMM of the NAR stages (mx_kernels.hpp) on caller-supplied fp32 operands: A (M, K) and W (N, K) are quantised on the
+// device exactly as the engine quantises activations / weights, then multiplied by mx256_kernel.  out_mode 0: C (M, N) fp32
+// [bias / ReLU]; 2: the FFN1 form - C as e4m3 bytes (M, N) in c_out and its E8M0 block scales (N/32, ld) in sc_out, ld = M
+// rounded up to 256.  qa_out / sa_out (optional): the quantised A bytes (M, K) and scales (K/32, ld), so that the quantiser
+// itself can be compared bit for bit with the host emulation (tests/mx_ref.py).
+extern "C" int vx_op_gemm_mx(const float* A, const float* Wt, const float* bias, void* c_out, void* sc_out, int32_t M, int32_t N,
+                             int32_t K, int32_t relu, int32_t out_mode, void* qa_out, void* sa_out, void* stream) {
+  if (!A || !Wt || !c_out || M < 1 || N % 256 || K % 128) return fail(VX_ERR_UNSUPPORTED, "mx gemm: M=%d N=%d K=%d (N %% 256, K %% 128)", M, N, K);
+  hipStream_t s = (hipStream_t)stream;
+  const int ld = (M + 255) / 256 * 256;
+  uint8_t *qa = nullptr, *sa = nullptr, *qw = nullptr, *sw = nullptr;
+  HIPC(hipMalloc((void**)&qa, (size_t)M * K)); HIPC(hipMalloc((void**)&sa, (size_t)(K / 32) * ld));
+  HIPC(hipMalloc((void**)&qw, (size_t)N * K)); HIPC(hipMalloc((void**)&sw, (size_t)(K / 32) * N));
+  HIPC(hipMemsetAsync(sa, 0, (size_t)(K / 32) * ld, s));
+  mx_quant_rows_kernel<<<(M + 3) / 4, 256, 0, s>>>(A, qa, sa, M, K, ld);
+  mx_quant_rows_kernel<<<(N + 3) / 4, 256, 0, s>>>(Wt, qw, sw, N, K, N);
+  int rc;
+  if (out_mode == 2) {
+    if (!sc_out) return fail(VX_ERR_ARG, "mx gemm: out_mode 2 needs sc_out");
+    HIPC(hipMemsetAsync(sc_out, 0, (size_t)(N / 32) * ld, s));
+    rc = mx_gemm_dispatch(qa, sa, ld, qw, sw, N, bias, c_out, (uint8_t*)sc_out, ld, M, N, K, GE_RELU, MX_OUT_MX, s);
+  } else {
+    rc = mx_gemm_dispatch(qa, sa, ld, qw, sw, N, bias, c_out, nullptr, 0, M, N, K, relu ? GE_RELU : (bias ? GE_BIAS : GE_PLAIN), MX_OUT_F32, s);
+  }
+  if (rc) return fail(VX_ERR_UNSUPPORTED, "mx gemm: no kernel instance (rc %d)", rc);
+  HIPC(hipGetLastError());
+  if (qa_out) HIPC(hipMemcpyAsync(qa_out, qa, (size_t)M * K, hipMemcpyDefault, s));
+  if (sa_out) HIPC(hipMemcpyAsync(sa_out, sa, (size_t)(K / 32) * ld, hipMemcpyDefault, s));
+  HIPC(hipStreamSynchronize(s));
+  (void)hipFree(qa); (void)hipFree(sa); (void)hipFree(qw); (void)hipFree(sw);
+  return VX_OK;
+}
+
+// (Adaptive)LayerNorm with an MXFP8 result (layernorm_rows_mx_kernel): q_out (rows, d) e4m3 bytes, s_out (d/32, ld) E8M0 bytes,
+// ld = rows rounded up to 256 (pad entries zeroed).
+extern "C" int vx_op_layernorm_mx(const float* x, const float* gamma, const float* beta, const float* ada_w, const float* ada_b,
+                                  void* q_out, void* s_out, int32_t rows, int32_t d, void* stream) {
+  if (d % 32 || d > 1024 || rows < 1) return fail(VX_ERR_UNSUPPORTED, "layernorm_mx: d=%d", d);
+  hipStream_t s = (hipStream_t)stream;
+  const int ld = (rows + 255) / 256 * 256;
+  HIPC(hipMemsetAsync(s_out, 0, (size_t)(d / 32) * ld, s));
+  layernorm_rows_mx_kernel<4><<<(rows + 3) / 4, 256, 0, s>>>(x, gamma, beta, ada_w, ada_b, (uint8_t*)q_out, (uint8_t*)s_out, rows, d, ld);
   HIPC(hipGetLastError());
   return VX_OK;
 }

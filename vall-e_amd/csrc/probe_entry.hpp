@@ -202,3 +202,28 @@ extern "C" int vx_debug_read_stamps(unsigned long long* out, int32_t n) {
   return fail(VX_ERR_UNSUPPORTED, "library built without -DVX_STAMPS (python vall-e_amd/csrc/build.py --stamps)");
 #endif
 }
+
+
+// In-graph stamps of the AR decode step (common.hpp VX_KSTAMP): dst == NULL (re)arms the device ring ([16 passes][64 kernels]
+// [1024 wave slots][entry, exit] x 8 bytes, zeroed); otherwise copies it to host memory.  dims = {16, 64, 1024, 2}.
+extern "C" int vx_debug_kstamps(void* dst, int64_t nbytes, int32_t* dims) {
+#ifdef VX_STAMPS
+  static unsigned long long* ring = nullptr;
+  const size_t bytes = (size_t)16 * 64 * 1024 * 2 * 8;
+  if (dims) { dims[0] = 16; dims[1] = 64; dims[2] = 1024; dims[3] = 2; }
+  HIPC(hipDeviceSynchronize());
+  if (dst == nullptr) {
+    if (!ring) HIPC(hipMalloc((void**)&ring, bytes));
+    HIPC(hipMemset(ring, 0, bytes));
+    HIPC(hipMemcpyToSymbol(HIP_SYMBOL(g_vx_kstamps), &ring, sizeof ring));
+    HIPC(hipDeviceSynchronize());
+    return VX_OK;
+  }
+  if (!ring) return fail(VX_ERR_STATE, "stamps not armed");
+  HIPC(hipMemcpy(dst, ring, (size_t)nbytes < bytes ? (size_t)nbytes : bytes, hipMemcpyDeviceToHost));
+  return VX_OK;
+#else
+  (void)dst; (void)nbytes; (void)dims;
+  return fail(VX_ERR_UNSUPPORTED, "library built without -DVX_STAMPS (python vall-e_amd/csrc/build.py --stamps)");
+#endif
+}

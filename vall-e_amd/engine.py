@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvallex.so")
 
-VX_PREC_F32, VX_PREC_BF16 = 0, 1
+VX_PREC_F32, VX_PREC_BF16, VX_PREC_FP8_NAR = 0, 1, 2
 BMAX = 64  # slots per engine (csrc/batch_kernels.hpp)
 VX_FLAG_TRACE_LOGITS, VX_FLAG_NO_GRAPH, VX_FLAG_SIMPLE_ROWS, VX_FLAG_POST_NORM, VX_FLAG_PRENET = 1, 2, 4, 8, 16
 STOP_REASONS = {0: "none", 1: "eos_argmax", 2: "eos_sample", 3: "length", 4: "max_new"}
@@ -69,6 +69,8 @@ _SIGS = {
     "vx_op_layernorm": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p]),
     "vx_op_gemv": (C.c_int, [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "vx_op_gemm": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
+    "vx_op_gemm_mx": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p] * 3),
+    "vx_op_layernorm_mx": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_void_p]),
     "vx_op_attention": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
     "vx_op_sample": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "vx_op_convert_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -153,14 +155,14 @@ class Engine:
         c.d_model, c.nhead, c.num_layers = cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers
         c.nar_d_model, c.nar_nhead, c.nar_num_layers = cfg.nar_dim, cfg.nar_nhead, cfg.nar_layers
         c.num_quantizers, c.prefix_mode, c.prepend_bos = cfg.num_quantizers, cfg.prefix_mode, int(cfg.prepend_bos)
-        c.precision = {"fp32": VX_PREC_F32, "f32": VX_PREC_F32, "bf16": VX_PREC_BF16}[precision]
+        c.precision = {"fp32": VX_PREC_F32, "f32": VX_PREC_F32, "bf16": VX_PREC_BF16, "fp8nar": VX_PREC_FP8_NAR}[precision]
         c.max_text, c.max_audio, c.device = max_text, max_audio, self.device
         c.flags = (VX_FLAG_TRACE_LOGITS if trace_logits else 0) | (VX_FLAG_NO_GRAPH if no_graph else 0) | \
                   (VX_FLAG_SIMPLE_ROWS if simple_rows else 0) | (0 if getattr(cfg, "norm_first", True) else VX_FLAG_POST_NORM) | \
                   (VX_FLAG_PRENET if getattr(cfg, "add_prenet", False) else 0)
         c.max_batch = int(max_batch)
         self.max_text, self.max_audio, self.trace_logits, self.max_batch = max_text, max_audio, trace_logits, int(max_batch)
-        self.mfma_rows = c.precision == VX_PREC_BF16 and not simple_rows
+        self.mfma_rows = c.precision != VX_PREC_F32 and not simple_rows
         h = C.c_void_p()
         _check(self.lib.vx_create(C.byref(c), C.byref(h)))
         self.h = h
@@ -359,6 +361,38 @@ def op_gemm(A, W, bias=None, relu=False, mfma=False):
     _check(lib.vx_op_gemm(_prec(A), int(mfma), _ptr(A), _ptr(W), _ptr(bias), _ptr(Cm), M, N, K, int(relu),
                           current_stream_ptr(A.device)))
     return Cm
+
+
+def op_gemm_mx(A, W, bias=None, relu=False, out_mx=False, return_quant=False):
+    """MXFP8 GEMM (vx_op_gemm_mx): fp32 A (M, K), W (N, K) on the GPU.  out_mx=False -> C (M, N) fp32; True -> (e4m3 bytes (M, N),
+    E8M0 scales (N/32, ld)) of ReLU(C + bias).  return_quant adds the engine's quantisation of A: (bytes (M, K), scales (K/32, ld))."""
+    lib = load_library()
+    M, K = A.shape
+    N = W.shape[0]
+    ld = (M + 255) // 256 * 256
+    dev = A.device
+    if out_mx:
+        c = torch.empty((M, N), dtype=torch.uint8, device=dev)
+        sc = torch.empty((N // 32, ld), dtype=torch.uint8, device=dev)
+    else:
+        c, sc = torch.empty((M, N), dtype=torch.float32, device=dev), None
+    qa = torch.empty((M, K), dtype=torch.uint8, device=dev) if return_quant else None
+    sa = torch.empty((K // 32, ld), dtype=torch.uint8, device=dev) if return_quant else None
+    _check(lib.vx_op_gemm_mx(_ptr(A), _ptr(W), _ptr(bias), _ptr(c), _ptr(sc), M, N, K, int(relu), 2 if out_mx else 0, _ptr(qa), _ptr(sa),
+                             current_stream_ptr(dev)))
+    res = (c, sc) if out_mx else c
+    return (res, qa, sa) if return_quant else res
+
+
+def op_layernorm_mx(x, gamma, beta, ada_w=None, ada_b=None):
+    lib = load_library()
+    rows, d = x.shape
+    ld = (rows + 255) // 256 * 256
+    q = torch.empty((rows, d), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((d // 32, ld), dtype=torch.uint8, device=x.device)
+    _check(lib.vx_op_layernorm_mx(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(ada_w), _ptr(ada_b), _ptr(q), _ptr(sc), rows, d,
+                                  current_stream_ptr(x.device)))
+    return q, sc
 
 
 def op_attention(qkv, nhead, text_len=-1, mfma=False):
