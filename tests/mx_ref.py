@@ -29,3 +29,14 @@ def mx_gemm_ref(A: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     a = mx_dequant(*mx_quant(A)).double()
     w = mx_dequant(*mx_quant(W)).double()
     return (a @ w.t()).float()
+
+
+def mx_spos(n_rows: int) -> torch.Tensor:
+    """position of row r's scale inside a k-block's run of the engine's scale arrays (mx_kernels.hpp mx_spos)."""
+    r = torch.arange(n_rows)
+    return (r & ~127) | ((r & 31) << 2) | ((r >> 5) & 3)
+
+
+def scales_by_row(sc: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """engine scale array (K/32, ld) -> (n_rows, K/32) in row order."""
+    return sc[:, mx_spos(n_rows)].t().contiguous()

@@ -198,6 +198,49 @@ def test_nar_stages_teacher_forced_margin_rule(name, precision):
         assert float(per_stage.min()) >= 0.95, per_stage
 
 
+FP8_REL_TOL = 0.08  # MXFP8 (e4m3, 3 mantissa bits, one power-of-two scale per 32 k) operands in the QKV / FFN GEMMs of 12 layers
+
+
+@pytest.mark.parametrize("name", ["cfg0_topk10", "cfg1_topk10"])
+def test_fp8_nar_stages_teacher_forced(name, monkeypatch):
+    """VX_PREC_FP8_NAR (BASELINE configs[4]): the NAR stages' QKV / FFN1 / FFN2 GEMMs on MXFP8, everything else bf16.  Same
+    protocol as the bf16 margin-rule test: every stage on the reference's inputs, logits of the recorded rows within the fp8
+    tolerance, argmax exact wherever the reference's margin exceeds twice that tolerance, and the measured agreement reported.
+    VX_MX_MIN_ROWS=1 sends one utterance's rows through the MXFP8 kernels (the product uses them from 4096 rows on)."""
+    from conftest import NarStats
+
+    monkeypatch.setenv("VX_MX_MIN_ROWS", "1")
+    g = Golden(name)
+    ns = NarStats(name)
+    m = _model(g, "fp8nar")
+    e = m.engine()
+    Q = g.cfg.num_quantizers
+    text, prompts = g.x[0], g.y[0, :, :Q].contiguous()
+    ref = g.codes[0]
+    codes, lg = e.nar(text, prompts, ref[:, 0].contiguous(), forced_codes=ref, stage_logits=True)
+    codes = codes.cpu()
+    worst = 0.0
+    for i in range(Q - 1):
+        err = (lg[i, ns.rows] - ns.row_logits[i]).abs().amax(1)
+        scale = ns.absmax[i, ns.rows]
+        worst = max(worst, float((err / scale).max()))
+    eq = (codes[:, 1:] == ref[:, 1:]).t()
+    decided = ns.decided(FP8_REL_TOL)
+    per_stage = eq.float().mean(1)
+    print(name, "fp8nar worst rel err %.4f" % worst, "decided %.3f" % float(decided.float().mean()),
+          "flipped decided rows %d" % int((~eq[decided]).sum()), "agreement per stage", [round(float(v), 4) for v in per_stage])
+    assert worst <= FP8_REL_TOL
+    assert bool(eq[decided].all()), f"{int((~eq[decided]).sum())} decided rows flipped"
+    assert float(per_stage.min()) >= 0.80, per_stage
+    # the same utterance four times through the batched NAR (4352 concatenated rows: the product's MXFP8 path without the knob)
+    monkeypatch.delenv("VX_MX_MIN_ROWS")
+    if g.cfg.decoder_dim >= 1024:
+        outs = e.nar_batch([text] * 4, [prompts] * 4, [ref[:, 0].contiguous()] * 4, forced_codes=[ref] * 4)
+        for o in outs:
+            eqb = (o.cpu()[:, 1:] == ref[:, 1:]).t()
+            assert bool(eqb[decided].all()) and float(eqb.float().mean(1).min()) >= 0.80
+
+
 @pytest.mark.parametrize("name", golden_names("continual"))
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_continual_matches_reference(name, precision):

@@ -150,7 +150,7 @@ def test_mx_gemm_matches_host_emulation(eng, M, N, K):
     """Quantiser: bit-exact bytes and scales.  GEMM: both operands dequantise to exact fp32 values and every product of two of them
     is exact in fp32, so the matrix core's result differs from an fp64 evaluation only by fp32 accumulation: tolerance 1e-5 of the
     row's magnitude budget sum |a||w|."""
-    from mx_ref import mx_dequant, mx_gemm_ref, mx_quant
+    from mx_ref import mx_dequant, mx_gemm_ref, mx_quant, mx_spos, scales_by_row
 
     A, W, b = _rand(M, K, seed=1, scale=1.7), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
     A[3, 5] = 300.0  # an outlier block and an all-zero block
@@ -159,8 +159,10 @@ def test_mx_gemm_matches_host_emulation(eng, M, N, K):
     C, qa, sa = eng.op_gemm_mx(A.cuda(), W.cuda(), b.cuda(), return_quant=True)
     q_ref, s_ref = mx_quant(A)
     assert torch.equal(qa.cpu(), q_ref)
-    assert torch.equal(sa.cpu()[:, :M].t().contiguous(), s_ref)
-    assert int(sa.cpu()[:, M:].max()) == 0 if ld > M else True
+    assert torch.equal(scales_by_row(sa.cpu(), M), s_ref)
+    unused = torch.ones(ld, dtype=torch.bool)
+    unused[mx_spos(M)] = False
+    assert int(sa.cpu()[:, unused].sum()) == 0  # pad entries stay zero (finite scales for the tile loader's clamped rows)
     ref = mx_gemm_ref(A, W) + b
     budget = mx_dequant(*mx_quant(A)).abs().double() @ mx_dequant(*mx_quant(W)).abs().double().t()
     assert bool(((C.cpu() - ref).abs().double() <= 1e-5 * budget + 1e-6).all())
@@ -173,12 +175,12 @@ def test_mx_gemm_matches_host_emulation(eng, M, N, K):
 
 def test_mx_gemm_quantised_output(eng):
     """FFN1's epilogue: ReLU(C + bias) leaves the GEMM as e4m3 bytes with one scale per 32 columns (the A operand of FFN2)."""
-    from mx_ref import mx_dequant, mx_gemm_ref, mx_quant
+    from mx_ref import mx_dequant, mx_gemm_ref, mx_quant, scales_by_row
 
     M, N, K = 700, 1024, 256
     A, W, b = _rand(M, K, seed=4), _rand(N, K, seed=5, scale=K ** -0.5), _rand(N, seed=6)
     (c8, sc) = eng.op_gemm_mx(A.cuda(), W.cuda(), b.cuda(), out_mx=True)
-    got = mx_dequant(c8.cpu(), sc.cpu()[:, :M].t().contiguous())
+    got = mx_dequant(c8.cpu(), scales_by_row(sc.cpu(), M))
     ref = (mx_gemm_ref(A, W) + b).clamp_min(0)
     # the kernel quantises ITS fp32 sums (accumulation order differs from the host's by ~1e-6): a value on a rounding boundary
     # may land one e4m3 step away, so compare dequantised values within one step (2^-3 relative) and require most to be equal
@@ -190,7 +192,7 @@ def test_mx_gemm_quantised_output(eng):
 @pytest.mark.parametrize("rows,d", [(300, 1024), (37, 256)])
 @pytest.mark.parametrize("adaptive", [False, True])
 def test_layernorm_mx(eng, rows, d, adaptive):
-    from mx_ref import mx_dequant, mx_quant
+    from mx_ref import mx_quant, scales_by_row
 
     x, g, b = _rand(rows, d, seed=1, scale=3.0), 1 + 0.1 * _rand(d, seed=2), 0.1 * _rand(d, seed=3)
     w, c = (1 + 0.1 * _rand(d, seed=4), 0.1 * _rand(d, seed=5)) if adaptive else (None, None)
@@ -198,5 +200,5 @@ def test_layernorm_mx(eng, rows, d, adaptive):
     f32 = eng.op_layernorm(dev(x), dev(g), dev(b), dev(w), dev(c), torch.float32).cpu()  # same arithmetic, unquantised
     q, sc = eng.op_layernorm_mx(dev(x), dev(g), dev(b), dev(w), dev(c))
     q_ref, s_ref = mx_quant(f32)
-    assert torch.equal(sc.cpu()[:, :rows].t().contiguous(), s_ref)
+    assert torch.equal(scales_by_row(sc.cpu(), rows), s_ref)
     assert torch.equal(q.cpu(), q_ref)

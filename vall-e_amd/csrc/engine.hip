@@ -749,6 +749,14 @@ static int split_for(int K) {  // K slices of the split-K GEMMs: a multiple of t
   return 1;
 }
 
+static bool use_mfma(const vx_engine* e);
+// VX_PREC_FP8_NAR: do this stage's QKV / FFN GEMMs run on MXFP8?  (NAR stages only, pre-norm, at or above the row threshold;
+// VX_MX_MIN_ROWS lowers it: the parity tests run one utterance's 1025 rows through the MXFP8 kernels)
+static bool mx_on(const vx_engine* e, int ada_stage, int M, int d) {
+  const char* v = getenv("VX_MX_MIN_ROWS");
+  return e->fp8nar && ada_stage >= 0 && M >= (v ? atoi(v) : 4096) && !(e->cfg.flags & VX_FLAG_POST_NORM) && use_mfma(e) && d % 256 == 0;
+}
+
 static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int d, int H, int text_len, int ada_stage,
                      bool fill_cache, char* kv_base = nullptr) {
   if (kv_base == nullptr) kv_base = (char*)e->kv;
@@ -758,9 +766,8 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
   // The two N = d GEMMs of a layer (out-projection, FFN2) at M ~ 1k rows: 128^2 tiles alone are 72 workgroups, so K is
   // split over 2-4 workgroups per tile, every slice writes an fp32 slab, and the LayerNorm that follows the GEMM anyway
   // adds bias + slabs to x in a fixed order.  Larger M (batched rows) has enough tiles and adds in the GEMM epilogue.
-  const bool splitk = use_mfma(e) && M < 4096 && M <= e->slab_rows && d % 128 == 0 && d >= 128;
-  // VX_PREC_FP8_NAR: the NAR stages' QKV / FFN GEMMs on MXFP8 once the row count reaches the 256-tile path (batched NAR)
-  const bool mx = e->fp8nar && ada_stage >= 0 && M >= 4096 && !post && use_mfma(e) && d % 256 == 0;
+  const bool splitk = use_mfma(e) && M < 4096 && M <= e->slab_rows && d % 128 == 0 && d >= 128 && !mx_on(e, ada_stage, M, d);
+  const bool mx = mx_on(e, ada_stage, M, d);
   const size_t sstride = (size_t)M * d;
   const int sp_d = split_for(d), sp_ff = split_for(4 * d);
   Fold pend;  // FFN2 slabs of the previous layer, folded by the next norm (pre-norm) or by the trailing fold pass

@@ -7,7 +7,8 @@
 // can quantise its own output (and the LayerNorm kernel its own row) with no extra pass over the activations.
 //
 // Operand storage:  bytes [rows][K] e4m3, K-contiguous;  scales [K/32][ld_s] E8M0 bytes (k-block major, ld_s >= rows rounded
-// up to 256 and zero-padded), so that the scales one 256-row tile needs for one 64-deep K stage are two runs of 256 bytes.
+// up to 256 and zero-padded; inside a k-block's run row r sits at mx_spos(r)), so that the scales one 256-row tile needs for one
+// 64-deep K stage are two runs of 256 bytes.
 // Quantisation (mx_block_scale / mx_pack4, mirrored by tests/mx_ref.py): with E the biased exponent of the block's largest
 // magnitude, scale byte = max(E, 8) - 8 (i.e. 2^(floor(log2 amax) - 8): e4m3's largest binade), values multiplied by the
 // exact inverse power of two, clamped to +-448 and rounded to nearest even by v_cvt_pk_fp8_f32.
@@ -18,6 +19,7 @@
 namespace vx {
 
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float group8_max_dpp(float v) {  // max over aligned groups of 8 lanes, in every lane of the group
   v = fmaxf(v, dpp_f<0xB1>(v, v));
@@ -25,6 +27,11 @@ __device__ __forceinline__ float group8_max_dpp(float v) {  // max over aligned 
   v = fmaxf(v, dpp_f<0x141>(v, v));
   return v;
 }
+// Position of a row's scale inside a k-block's run of the scale array: rows r, r + 32, r + 64, r + 96 of every 128-row group sit
+// in one dword, so a lane of the GEMM reads the scales of its four A fragments (two W fragments) with one LDS read and picks
+// the byte with the MFMA's op_sel.
+__host__ __device__ __forceinline__ int mx_spos(int row) { return (row & ~127) | ((row & 31) << 2) | ((row >> 5) & 3); }
+
 __device__ __forceinline__ uint32_t mx_block_scale(float amax, float& inv) {
   const uint32_t E = (__float_as_uint(amax) >> 23) & 0xffu;
   const uint32_t byte = max(E, 8u) - 8u;
@@ -53,7 +60,7 @@ __global__ __launch_bounds__(256) void mx_quant_rows_kernel(const float* __restr
     const uint32_t sb = mx_block_scale(am, inv);
     if (ok) {
       *reinterpret_cast<uint32_t*>(q + (size_t)r * K + k) = mx_pack4(v.x, v.y, v.z, v.w, inv);
-      if ((lane & 7) == 0) sc[(size_t)(k >> 5) * ld_s + r] = (uint8_t)sb;
+      if ((lane & 7) == 0) sc[(size_t)(k >> 5) * ld_s + mx_spos(r)] = (uint8_t)sb;
     }
   }
 }
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_mx_kernel(const float* x, 
     const uint32_t sb = mx_block_scale(am, inv);
     if (ok[i]) {
       *reinterpret_cast<uint32_t*>(q + (size_t)r * d + kk[i]) = mx_pack4(o[0], o[1], o[2], o[3], inv);
-      if ((lane & 7) == 0) sc[(size_t)(kk[i] >> 5) * ld_s + r] = (uint8_t)sb;
+      if ((lane & 7) == 0) sc[(size_t)(kk[i] >> 5) * ld_s + mx_spos(r)] = (uint8_t)sb;
     }
   }
 }
@@ -125,8 +132,8 @@ __global__ __launch_bounds__(256) void layernorm_rows_mx_kernel(const float* x, 
 // in its 32 operand bytes, and the scale byte it supplies applies to exactly those 32 values.
 // The MFMA is issued as (W fragment, A fragment), so the accumulator has m on the lane and n = (v&3) + 8 (v>>2) + 4 h in its
 // registers: 4 consecutive n per register quad.
-// Per stage the ring slot also carries the stage's 2 x 256 scale bytes of each operand (waves 0-3 issue one extra 4-byte-per-lane
-// LDS-DMA: waves 0/1 the A scales of k-blocks 2s / 2s+1, waves 2/3 the W scales).
+// Per stage the ring slot also carries the stage's 2 x 256 scale bytes of each operand (every wave brings 128 of the 1024 bytes
+// with one 2-byte-per-lane LDS-DMA).
 enum MxOut { MX_OUT_F32 = 0, MX_OUT_BF16 = 1, MX_OUT_MX = 2 };
 
 template <int EPI, int OUT>
@@ -137,7 +144,9 @@ __global__ __launch_bounds__(512) void mx256_kernel(const uint8_t* __restrict__ 
                                                     bf16* __restrict__ vt, int vt_n0, int vt_ld, int ntn, int ntiles) {
   constexpr int STAGE = 32768 + 1024;  // A 16 KB | W 16 KB | A scales 2 x 256 | W scales 2 x 256
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // `wave` in an SGPR: the branches on it below enclose scalar instructions (s_waitcnt / s_barrier / the LDS-DMA's M0 setup),
+  // which ignore EXEC - under a branch the compiler takes for divergent a wave would run BOTH sides' waits and barriers
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 31, h = lane >> 5;
   const int G = gridDim.x;
@@ -166,9 +175,14 @@ __global__ __launch_bounds__(512) void mx256_kernel(const uint8_t* __restrict__ 
     srcA1 = A + (size_t)min(mt * 256 + rowa1, M - 1) * K + ca1;
     srcW0 = W + (size_t)min(nt * 256 + rowa0, N - 1) * K + ca0;
     srcW1 = W + (size_t)min(nt * 256 + rowa1, N - 1) * K + ca1;
-    // waves 0-3: 4 scale bytes per lane = rows 4 lane .. 4 lane + 3 of k-block 2 s + (wave & 1); the arrays are padded to 256 rows
-    if (wave < 2) { srcS = SA + (size_t)(wave & 1) * lda_s + mt * 256 + lane * 4; s_step = (size_t)2 * lda_s; }
-    else { srcS = SW + (size_t)(wave & 1) * ldw_s + nt * 256 + lane * 4; s_step = (size_t)2 * ldw_s; }
+    // scales: the stage's block is [A kb0 | A kb1 | W kb0 | W kb1] x 256 bytes = one 16-byte LDS-DMA load of one wave; every
+    // wave issues it (same bytes to the same place), so that all waves run the same five loads per stage: one counted wait, no
+    // branch in the loop, and only 16-byte LDS-DMA in the kernel (a narrower one next to the ds_reads made hipcc drain vmcnt(0))
+    {
+      const int part = lane >> 4, off = (lane & 15) * 16;
+      if (part < 2) { srcS = SA + (size_t)part * lda_s + mt * 256 + off; s_step = (size_t)2 * lda_s; }
+      else { srcS = SW + (size_t)(part - 2) * ldw_s + nt * 256 + off; s_step = (size_t)2 * ldw_s; }
+    }
   };
   auto stage = [&]() {
     unsigned char* base = lds + (l_slot & 3) * STAGE;
@@ -181,74 +195,68 @@ __global__ __launch_bounds__(512) void mx256_kernel(const uint8_t* __restrict__ 
                                      (__attribute__((address_space(3))) void*)(base + 16384 + d0), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW1 + k0),
                                      (__attribute__((address_space(3))) void*)(base + 16384 + d1), 16, 0, 0);
-    if (wave < 4)  // wave-uniform: [A scales kb0 | A scales kb1 | W scales kb0 | W scales kb1], 256 bytes each
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcS + (size_t)l_k * s_step),
-                                       (__attribute__((address_space(3))) void*)(base + 32768 + wave * 256), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcS + (size_t)l_k * s_step),
+                                     (__attribute__((address_space(3))) void*)(base + 32768), 16, 0, 0);
     ++l_slot;
     if (++l_k == nk) { l_k = 0; set_load_tile(++l_ord); }
   };
 
+  // Registers: 128 accumulators leave room for ONE and a half stages of fragments, not two: the W fragments (and the scale
+  // dwords) of the current and of the next stage live in two named sets, the A fragments in two halves (rows i = 0,1 / 2,3) that
+  // are refilled one half-stage (4 MFMAs = 256 matrix cycles) ahead of their use.
   f32x16_t acc[4][2];
-  struct Frags { uint4 a[4][2], w[2][2]; unsigned sa[4], sw[2]; };
-  Frags fA, fB;
-  auto lread = [&](int slot, Frags& f) {
-    const unsigned char* ba = lds + (slot & 3) * STAGE;
-    const unsigned char* bw = ba + 16384;
-    const unsigned char* bs = ba + 32768 + h * 256;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = wn * 64 + j * 32 + r, sw = (0 - (row >> 2)) & 3;
-      f.w[j][0] = *reinterpret_cast<const uint4*>(bw + row * 64 + (((2 * h) ^ sw) << 4));
-      f.w[j][1] = *reinterpret_cast<const uint4*>(bw + row * 64 + (((2 * h + 1) ^ sw) << 4));
-      f.sw[j] = bs[512 + row];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = wm * 128 + i * 32 + r, sw = (0 - (row >> 2)) & 3;
-      f.a[i][0] = *reinterpret_cast<const uint4*>(ba + row * 64 + (((2 * h) ^ sw) << 4));
-      f.a[i][1] = *reinterpret_cast<const uint4*>(ba + row * 64 + (((2 * h + 1) ^ sw) << 4));
-      f.sa[i] = bs[row];
-    }
-  };
-  auto frag = [](const uint4 (&p)[2]) {
+  u32x4 w0[2][2], w1[2][2], aX[2][2], aY[2][2];
+  unsigned sw0 = 0, sw1 = 0, sa0 = 0, sa1 = 0;
+  auto frag = [](const u32x4 (&p)[2]) {
     i32x8_t v;
     v[0] = (int)p[0].x; v[1] = (int)p[0].y; v[2] = (int)p[0].z; v[3] = (int)p[0].w;
     v[4] = (int)p[1].x; v[5] = (int)p[1].y; v[6] = (int)p[1].z; v[7] = (int)p[1].w;
     return v;
   };
-  auto mm = [&](const Frags& f) {
+  auto read_w = [&](int slot, u32x4 (&w)[2][2], unsigned& sw, unsigned& sa) {
+    const unsigned char* ba = lds + (slot & 3) * STAGE;
+    const unsigned char* bw = ba + 16384;
+    const unsigned char* bs = ba + 32768 + h * 256;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(f.w[j]), frag(f.a[i]), acc[i][j], 0, 0, 0, (int)f.sw[j], 0,
-                                                                    (int)f.sa[i]);
+    for (int j = 0; j < 2; ++j) {
+      const int row = wn * 64 + j * 32 + r, sz = (0 - (row >> 2)) & 3;
+      w[j][0] = *reinterpret_cast<const u32x4*>(bw + row * 64 + (((2 * h) ^ sz) << 4));
+      w[j][1] = *reinterpret_cast<const u32x4*>(bw + row * 64 + (((2 * h + 1) ^ sz) << 4));
+    }
+    // the scale dwords of this lane: bytes i = 0..3 are rows r + 32 i of the wave's 128-row group (mx_spos)
+    sa = *reinterpret_cast<const unsigned*>(bs + wm * 128 + r * 4);
+    sw = *reinterpret_cast<const unsigned*>(bs + 512 + (wn >> 1) * 128 + r * 4) >> ((wn & 1) * 16);  // bytes 0,1 = fragments j = 0,1
   };
-  // the 4-5 LDS-DMA loads and the 18 fragment / scale reads of the NEXT stage are spread between the 8 MFMAs of the current one
-  auto interleave = [&]() {
+  auto read_a = [&](int slot, int half, u32x4 (&a)[2][2]) {
+    const unsigned char* ba = lds + (slot & 3) * STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x010, 3, 0);  // VMEM
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // DS read
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      const int row = wm * 128 + (2 * half + i) * 32 + r, sz = (0 - (row >> 2)) & 3;
+      a[i][0] = *reinterpret_cast<const u32x4*>(ba + row * 64 + (((2 * h) ^ sz) << 4));
+      a[i][1] = *reinterpret_cast<const u32x4*>(ba + row * 64 + (((2 * h + 1) ^ sz) << 4));
     }
   };
-  // counted wait: the youngest stage (4 loads, 5 in waves 0-3) may stay in flight across the barrier
-  auto wait_barrier = [&]() {
-    if (wave < 4) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-  };
+  // 4 MFMAs: A fragments 2 half .. 2 half + 1 against both W fragments (op_sel = byte of the scale dword)
+#define MX_MM(HALF, W, SW, A, SA)                                                                                                   \
+  do {                                                                                                                             \
+    acc[2 * HALF][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(W[0]), frag(A[0]), acc[2 * HALF][0], 0, 0, 0, (int)SW, 2 * HALF, (int)SA);         \
+    acc[2 * HALF][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(W[1]), frag(A[0]), acc[2 * HALF][1], 0, 0, 1, (int)SW, 2 * HALF, (int)SA);         \
+    acc[2 * HALF + 1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(W[0]), frag(A[1]), acc[2 * HALF + 1][0], 0, 0, 0, (int)SW, 2 * HALF + 1, (int)SA); \
+    acc[2 * HALF + 1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(W[1]), frag(A[1]), acc[2 * HALF + 1][1], 0, 0, 1, (int)SW, 2 * HALF + 1, (int)SA); \
+  } while (0)
+  // counted wait: the youngest stage (5 loads per wave) may stay in flight across the barrier
+  auto wait_barrier = [&]() { asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory"); };
 
+  // Stage s of the stream lives in ring slot s & 3.  On stage s: [issue stage s+3] [read A rows 2,3 of s] [MFMAs rows 0,1]
+  // [read W + scales + A rows 0,1 of stage s+1] [MFMAs rows 2,3] [vmcnt: stage s+2 landed] [barrier].  Slot (s+3)&3 = (s-1)&3
+  // was last read (A rows 2,3) during stage s-1, whose MFMAs consumed those reads before that stage's barrier.
   set_load_tile(0);
   stage();
   stage();
   stage();
   wait_barrier();  // stages 0 and 1 landed everywhere
-  lread(0, fA);
+  read_w(0, w0, sw0, sa0);
+  read_a(0, 0, aX);
   int c_slot = 0;
   for (int ord = 0; ord < cnt; ++ord) {
     const int tile = tile_of((int)blockIdx.x + ord * G);
@@ -262,17 +270,22 @@ __global__ __launch_bounds__(512) void mx256_kernel(const uint8_t* __restrict__ 
         for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
     for (int t = 0; t < nk; t += 2) {  // nk is even (K % 128 == 0)
       stage();
-      lread(c_slot + 1, fB);
-      mm(fA);
-      interleave();
+      read_a(c_slot, 1, aY);
+      MX_MM(0, w0, sw0, aX, sa0);
+      read_w(c_slot + 1, w1, sw1, sa1);
+      read_a(c_slot + 1, 0, aX);
+      MX_MM(1, w0, sw0, aY, sa0);
       wait_barrier();
       stage();
-      lread(c_slot + 2, fA);
-      mm(fB);
-      interleave();
+      read_a(c_slot + 1, 1, aY);
+      MX_MM(0, w1, sw1, aX, sa1);
+      read_w(c_slot + 2, w0, sw0, sa0);
+      read_a(c_slot + 2, 0, aX);
+      MX_MM(1, w1, sw1, aY, sa1);
       wait_barrier();
       c_slot += 2;
     }
+#undef MX_MM
 
     // epilogue: acc[i][j][v] = C[m = m0 + wm*128 + i*32 + r][n = n0 + wn*64 + j*32 + (v&3) + 8*(v>>2) + 4*h]
 #pragma unroll
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(512) void mx256_kernel(const uint8_t* __restrict__ 
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd)
               *reinterpret_cast<uint32_t*>(cp + 8 * qd) = mx_pack4(x[4 * qd], x[4 * qd + 1], x[4 * qd + 2], x[4 * qd + 3], inv);
-            if (h == 0) SC[(size_t)(nf >> 5) * ldc_s + m] = (uint8_t)sb;
+            if (h == 0) SC[(size_t)(nf >> 5) * ldc_s + mx_spos(m)] = (uint8_t)sb;
           }
         } else if (m < M) {
           if (OUT == MX_OUT_F32) {
