@@ -3,10 +3,10 @@
     python vall-e_amd/csrc/build.py --stamps && python tests/probes/ar_step_stamps.py [out.json]
 
 Runs the bench workload (BASELINE configs[1]: d=1024 L=12 bf16, S=47, P=225, top-k 10) on libvallex_stamps.so, whose decode
-kernels record s_memrealtime (100 MHz) at wave start and wave end into a 16-pass ring (common.hpp VX_KSTAMP).  Per kernel of
-the step: entry = first wave's start, exit = last wave's end; body = exit - entry; gap = next kernel's entry - this exit (the
-launch boundary as the kernels see it).  The sum over the 62 kernels + 62 gaps is the step period, checked against the HIP-event
-step time of the same run (vx_get_timings) and quoted next to the un-stamped library's step time (bench.py).
+kernels record s_memrealtime (100 MHz) into a 16-pass ring (common.hpp VX_KSTAMP): one wave of workgroup 0 its (slightly late)
+start, and in mode 2 one wave of the last workgroup its end.  period = next kernel's entry - this kernel's entry (mode 1, the
+least intrusive); body / gap = the split of that period by the mode-2 exit stamps.  The periods sum to the step, checked against
+the HIP-event step time of the same run (vx_get_timings) and quoted next to the un-stamped library's step time (bench.py).
 """
 import json
 import os
@@ -42,53 +42,68 @@ for i in range(2):  # warm-up (graph capture, clocks)
 
 names = ["sample+embed"] + [f"L{l}.{k}" for l in range(L) for k in ("qkv", "attn", "out", "ffn1", "ffn2")] + ["head"]
 NK = len(names)  # 62
-res = []
-for rep, n_new in enumerate((200, 400, 600, 753)):  # stop the decode at different context lengths: the ring holds its last 16 passes
-    assert lib.vx_debug_kstamps(None, 0, None) == 0
-    torch.manual_seed(77 + rep)
+
+
+def collect(mode, n_new, seed):
+    """one decode stopped after n_new tokens with the stamps armed in `mode`; the ring then holds its last 16 passes."""
+    assert lib.vx_debug_kstamps(None, mode, None) == 0
+    torch.manual_seed(seed)
     m.inference(x, xl, y, None, top_k=10, max_new_tokens=n_new)
     t = eng.timings()
-    ring = np.zeros((16, 64, 1024, 2), dtype=np.uint64)
+    ring = np.zeros((16, 64, 2), dtype=np.uint64)
     assert lib.vx_debug_kstamps(ring.ctypes.data_as(C.c_void_p), ring.nbytes, None) == 0
     ring = ring[:, :NK].astype(np.int64)
-    valid = ring[..., 0] > 0
-    entry = np.where(valid, ring[..., 0], np.iinfo(np.int64).max).min(axis=2)  # (16, NK)
-    exit_ = np.where(valid, ring[..., 1], 0).max(axis=2)
+    entry, exit_ = ring[..., 0], ring[..., 1]  # (16, NK): workgroup 0's stamp / the last workgroup's end stamp (mode 2)
+    valid = (entry > 0)[..., None]
     ok = valid.any(axis=2).all(axis=1)
-    # passes in time order; drop the oldest two and the newest two (the last step stops early)
-    order = [p for p in np.argsort(entry[:, 0]) if ok[p]][2:-2]
-    body = np.array([(exit_[p] - entry[p]) for p in order]) * 0.01          # us
-    gap_in = np.array([(entry[p][1:] - exit_[p][:-1]) for p in order]) * 0.01
-    period = np.diff(np.array([entry[p][0] for p in order])) * 0.01
-    step_gap = np.array([entry[order[i + 1]][0] - exit_[order[i]][NK - 1] for i in range(len(order) - 1)]) * 0.01
-    res.append(dict(ctx_end=47 + 225 + n_new, passes_used=len(order), hip_event_step_us=1e3 * t["decode_ms"] / t["launches"],
-                    period_us=float(period.mean()), body_us=body.mean(0).tolist(), gap_us=gap_in.mean(0).tolist() + [float(step_gap.mean())]))
+    order = [p for p in np.argsort(entry[:, 0]) if ok[p]][2:-2]  # time order; drop the oldest two and the newest two (the last step stops early)
+    return entry, exit_, order, 1e3 * t["decode_ms"] / t["launches"]
 
-# aggregate over the four context lengths
-body = np.mean([r["body_us"] for r in res], axis=0)
-gap = np.mean([r["gap_us"] for r in res], axis=0)
+
+CTX = (200, 400, 600, 753)
+# mode 1: entry stamps only -> per-kernel period = next kernel's entry - this kernel's entry
+per1, hip1 = [], []
+for rep, n_new in enumerate(CTX):
+    entry, _, order, hip_us = collect(1, n_new, 77 + rep)
+    seq = np.array([np.concatenate([entry[order[i]], entry[order[i + 1]][:1]]) for i in range(len(order) - 1)])
+    per1.append(np.diff(seq, axis=1).mean(0) * 0.01)
+    hip1.append(hip_us)
+period = np.mean(per1, axis=0)  # (NK,) us
+# mode 2: entry + exit -> how a period splits into body and gap (this mode's trailing store inflates the step: ratios only)
+body2, gap2, hip2 = [], [], []
+for rep, n_new in enumerate(CTX):
+    entry, exit_, order, hip_us = collect(2, n_new, 177 + rep)
+    body2.append(np.array([(exit_[p] - entry[p]) for p in order]).mean(0) * 0.01)
+    g_in = np.array([(entry[p][1:] - exit_[p][:-1]) for p in order]).mean(0) * 0.01
+    g_step = np.mean([entry[order[i + 1]][0] - exit_[order[i]][NK - 1] for i in range(len(order) - 1)]) * 0.01
+    gap2.append(np.concatenate([g_in, [g_step]]))
+    hip2.append(hip_us)
+body2, gap2 = np.mean(body2, axis=0), np.mean(gap2, axis=0)
+share = body2 / (body2 + gap2)
+body, gap = period * share, period * (1 - share)
+
 kinds = {}
 for i, n in enumerate(names):
     k = n.split(".")[-1]
-    kinds.setdefault(k, dict(count=0, body_us=0.0, gap_after_us=0.0))
-    kinds[k]["count"] += 1
-    kinds[k]["body_us"] += float(body[i])
-    kinds[k]["gap_after_us"] += float(gap[i])
-for k in kinds.values():
-    k["body_us_each"] = round(k["body_us"] / k["count"], 3)
-    k["gap_after_us_each"] = round(k["gap_after_us"] / k["count"], 3)
-    k["body_us"] = round(k["body_us"], 2)
-    k["gap_after_us"] = round(k["gap_after_us"], 2)
+    d = kinds.setdefault(k, dict(count=0, period_us=0.0, body_us=0.0, gap_after_us=0.0))
+    d["count"] += 1
+    d["period_us"] += float(period[i]); d["body_us"] += float(body[i]); d["gap_after_us"] += float(gap[i])
+for d in kinds.values():
+    for f in ("period_us", "body_us", "gap_after_us"):
+        d[f + "_each"] = round(d[f] / d["count"], 3)
+        d[f] = round(d[f], 2)
 out = dict(
-    what="AR decode step, batch 1, cfg1 (d=1024 L=12 bf16): in-graph s_memrealtime stamps of the 62 kernels, mean over passes near ctx 472 / 672 / 872 / 1025",
-    kernels=NK, sum_body_us=round(float(body.sum()), 2), sum_gap_us=round(float(gap.sum()), 2),
-    sum_us=round(float(body.sum() + gap.sum()), 2),
-    stamped_period_us=round(float(np.mean([r["period_us"] for r in res])), 2),
-    stamped_hip_event_step_us=round(float(np.mean([r["hip_event_step_us"] for r in res])), 2),
-    by_kind=kinds, per_kernel=[dict(name=n, body_us=round(float(b), 3), gap_after_us=round(float(g), 3)) for n, b, g in zip(names, body, gap)],
-    per_context=[dict(ctx_end=r["ctx_end"], period_us=round(r["period_us"], 2), hip_event_step_us=round(r["hip_event_step_us"], 2)) for r in res],
+    what=("AR decode step, batch 1, cfg1 (d=1024 L=12 bf16), inside the hipGraph replay: s_memrealtime stamps of the 62 kernels, mean over "
+          "passes near ctx 472 / 672 / 872 / 1025.  period = entry-to-next-entry from the entry-only build (mode 1); its split into "
+          "body (first wave's start .. last wave's end) and gap from the entry+exit build (mode 2, whose trailing stores lengthen the step)"),
+    kernels=NK, sum_period_us=round(float(period.sum()), 2), sum_body_us=round(float(body.sum()), 2), sum_gap_us=round(float(gap.sum()), 2),
+    hip_event_step_us_mode1=round(float(np.mean(hip1)), 2), hip_event_step_us_mode2=round(float(np.mean(hip2)), 2),
+    by_kind=kinds,
+    per_kernel=[dict(name=n, period_us=round(float(p_), 3), body_us=round(float(b), 3), gap_after_us=round(float(g), 3))
+                for n, p_, b, g in zip(names, period, body, gap)],
+    per_context=[dict(ctx_end=47 + 225 + c, hip_event_step_us=round(h, 2), sum_period_us=round(float(p_.sum()), 2)) for c, h, p_ in zip(CTX, hip1, per1)],
 )
 s = json.dumps(out, indent=1)
 if len(sys.argv) > 1:
     open(sys.argv[1], "w").write(s + "\n")
-print(json.dumps({k: out[k] for k in ("sum_body_us", "sum_gap_us", "sum_us", "stamped_period_us", "stamped_hip_event_step_us", "by_kind")}))
+print(json.dumps({k: out[k] for k in ("sum_period_us", "sum_body_us", "sum_gap_us", "hip_event_step_us_mode1", "hip_event_step_us_mode2", "by_kind")}))

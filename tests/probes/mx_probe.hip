@@ -1,5 +1,10 @@
 // Probe (not product): operand / scale lane maps of v_mfma_scale_f32_32x32x64_f8f6f4 and _16x16x128_ on gfx950, checked with
 // exact integer data (cdna_hip_programming.md §3: "check the map with exact integer data before relying on it").
+// Findings (MI355X, ROCm 7.2): accumulator = [first operand's row: (v&3)+8(v>>2)+4h][second operand's row: lane&31]; op_sel picks
+// the byte of the scale register; a sum over k is invariant under any byte->k map shared by both operands, so the k map only
+// shows with UNEQUAL block scales (test 3b): lane (r, h) bytes 0-15 are k = 16h.., bytes 16-31 are k = 32+16h.., and the scale of
+// lane (r, h) applies to k-block h = bytes 16h..16h+15 of both lanes of the row.  v_cvt_pk_fp8_f32 is OCP e4m3 without saturation
+// (480 -> NaN): clamp to +-448 first.
 //   hipcc --offload-arch=gfx950 -O2 -o /tmp/mx_probe tests/probes/mx_probe.hip && /tmp/mx_probe
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -109,6 +114,20 @@ int main() {
   std::fill(sa.begin(), sa.end(), 0x7f7f807f); std::fill(sb.begin(), sb.end(), 0x7f817f7f);
   run32(0, 1);
   printf("opsel a=1 (byte1 = 128), b=2 (byte2 = 129): D[0][0] = %g (expect 64 * 2 * 4 = 512)\n", D[0]);
+  // (3b) one-hot A in the h = 1 half, zero blocks carrying scale byte 0 (2^-127): what vx_op_gemm_mx feeds for a one-hot row
+  {
+    for (int i = 0; i < M * K; ++i) { A[i] = 0x00; B[i] = enc(1 + (i % 64) % 4); }
+    for (int m = 0; m < 32; ++m) A[m * 64 + 37] = 0x78;  // 256
+    for (int l = 0; l < 64; ++l) { sa[l] = l < 32 ? 0x00000000 : 0x77777777; sb[l] = 0x7f7f7f7f; }
+    run32(0, 0);
+    printf("one-hot k=37 (value 256 x 2^-8), zero half with scale byte 0: D[0][0] = %g (expect %g)\n", D[0], (double)(1 + 37 % 4));
+    for (int l = 0; l < 64; ++l) sa[l] = l < 32 ? 0x7f7f7f7f : 0x77777777;
+    run32(0, 0);
+    printf("same with scale byte 127 on the zero half: D[0][0] = %g\n", D[0]);
+    for (int l = 0; l < 64; ++l) sa[l] = l < 32 ? 0x01010101 : 0x77777777;
+    run32(0, 0);
+    printf("same with scale byte 1 on the zero half: D[0][0] = %g\n", D[0]);
+  }
   // (4) 16x16x128
   {
     std::vector<uint8_t> A2(16 * 128), B2(16 * 128); std::vector<int> A2i(16 * 128), B2i(16 * 128);

@@ -165,28 +165,36 @@ def test_mx_gemm_matches_host_emulation(eng, M, N, K):
     assert int(sa.cpu()[:, unused].sum()) == 0  # pad entries stay zero (finite scales for the tile loader's clamped rows)
     ref = mx_gemm_ref(A, W) + b
     budget = mx_dequant(*mx_quant(A)).abs().double() @ mx_dequant(*mx_quant(W)).abs().double().t()
-    assert bool(((C.cpu() - ref).abs().double() <= 1e-5 * budget + 1e-6).all())
+    ratio = float(((C.cpu() - ref).abs().double() / (budget + 1e-3)).max())
+    print(M, N, K, "max |C - ref| / sum|a||w| = %.2e" % ratio)
+    assert ratio <= 2e-5  # fp32 accumulation inside the matrix core (block sums of 32 products, then across blocks / k-steps)
     Cr = eng.op_gemm_mx(A.cuda(), W.cuda(), b.cuda(), relu=True).cpu()
-    assert bool(((Cr - ref.clamp_min(0)).abs().double() <= 1e-5 * budget + 1e-6).all())
+    assert float(((Cr - ref.clamp_min(0)).abs().double() / (budget + 1e-3)).max()) <= 2e-5
     # the quantisation error itself, for the record: relative to the fp32 product
     exact = F.linear(A.double(), W.double(), b.double()).float()
     print(M, N, K, "mxfp8 vs fp32 GEMM: rel. error %.4f of the output rms" % float((ref - exact).pow(2).mean().sqrt() / exact.pow(2).mean().sqrt()))
 
 
 def test_mx_gemm_quantised_output(eng):
-    """FFN1's epilogue: ReLU(C + bias) leaves the GEMM as e4m3 bytes with one scale per 32 columns (the A operand of FFN2)."""
-    from mx_ref import mx_dequant, mx_gemm_ref, mx_quant, scales_by_row
+    """FFN1's epilogue: ReLU(C + bias) leaves the GEMM as e4m3 bytes with one scale per 32 columns (the A operand of FFN2).  Checked
+    against the same kernel's fp32 output x = ReLU(C + bias): every dequantised value within e4m3's rounding of x under its block's
+    scale (half an ulp = x / 16 for normals, 2^-10 scale units for subnormals, up to x / 8 where the block maximum's mantissa
+    exceeds 1.75 and the top clips to 448), and the scales equal to the host quantiser's on x (a block whose maximum sits within
+    rounding of a power of two may differ by one)."""
+    from mx_ref import mx_dequant, mx_quant, scales_by_row
 
     M, N, K = 700, 1024, 256
     A, W, b = _rand(M, K, seed=4), _rand(N, K, seed=5, scale=K ** -0.5), _rand(N, seed=6)
     (c8, sc) = eng.op_gemm_mx(A.cuda(), W.cuda(), b.cuda(), out_mx=True)
-    got = mx_dequant(c8.cpu(), scales_by_row(sc.cpu(), M))
-    ref = (mx_gemm_ref(A, W) + b).clamp_min(0)
-    # the kernel quantises ITS fp32 sums (accumulation order differs from the host's by ~1e-6): a value on a rounding boundary
-    # may land one e4m3 step away, so compare dequantised values within one step (2^-3 relative) and require most to be equal
-    want = mx_dequant(*mx_quant(ref))
-    assert bool(((got - want).abs() <= 0.13 * want.abs() + 1e-6).all())
-    assert float((got == want).float().mean()) >= 0.999
+    x = eng.op_gemm_mx(A.cuda(), W.cuda(), b.cuda(), relu=True).cpu()
+    sc_rows = scales_by_row(sc.cpu(), M)
+    got = mx_dequant(c8.cpu(), sc_rows)
+    amax = x.reshape(M, N // 32, 32).abs().amax(-1).repeat_interleave(32, dim=1)
+    assert bool(((got - x).abs() <= torch.maximum(0.1251 * x.abs(), amax * 2.0 ** -17) + 1e-7).all())
+    q_ref, s_ref = mx_quant(x)
+    assert float((sc_rows == s_ref).float().mean()) >= 0.999 and int((sc_rows.int() - s_ref.int()).abs().max()) <= 1
+    same_scale = (sc_rows == s_ref).repeat_interleave(32, dim=1)
+    assert float((c8.cpu() == q_ref)[same_scale].float().mean()) >= 0.999  # same fp32 sums -> same bytes (different ones: see above)
 
 
 @pytest.mark.parametrize("rows,d", [(300, 1024), (37, 256)])

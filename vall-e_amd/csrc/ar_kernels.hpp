@@ -50,6 +50,7 @@ struct GemvArgs {
   const void* pf;
   unsigned pf_slice, pf_total;
   int kid;  // position in the decode step (probe builds: VX_KSTAMP; -1 = not stamped)
+  int nt;   // non-temporal weight loads (decode step, VX_AR_NT)
 };
 
 // y = W x (+epilogue).  One wave owns RPW rows at a time; a row is KCH 16-byte loads per lane;
@@ -59,7 +60,8 @@ struct GemvArgs {
 // available), so those loads do not wait for a kernarg fetch - one memory round trip per wave otherwise.  hipcc does not
 // preload by-value structs, so GemvArgs alone would not qualify; everything else is read from it after the weight loads
 // are out.   xin = a.part for PRO_ATTN, a.x otherwise;  nk = (N << 16) | K.
-template <typename WT, int KCH, int RPW, int PRO, int NPF = 0>
+// NT: the weight stream uses non-temporal loads (global_load_dwordx4 ... nt): each weight byte is read once per token by one CU.
+template <typename WT, int KCH, int RPW, int PRO, int NPF = 0, bool NT = false>
 __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ W_, const float* __restrict__ xin,
                                                    const float* __restrict__ gamma_, const float* __restrict__ beta_,
                                                    unsigned nk, const GemvArgs a) {
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ W_, 
 #pragma unroll
       for (int c = 0; c < KCH; ++c) {
         const int k = min((c * 64 + lane) * VEC, K - VEC);
-        w[r][c] = ld16(W + (size_t)row * K + k);
+        w[r][c] = NT ? ld16nt(W + (size_t)row * K + k) : ld16(W + (size_t)row * K + k);
       }
     }
   };
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ W_, 
   // own arguments does not also wait for these
   int st_row = 0, st_pass = 0, st_trace = 0, st_done = 0, st_S = 0;
   if (st_) { st_row = st_->row; st_pass = st_->pass; st_trace = st_->trace_logits; st_done = st_->done; st_S = st_->S; }
+  VX_KSTAMP_ENTRY(a.kid, st_pass);
 
   // ---- (C) activation prologue in registers ---------------------------------------------------
   float xr[KCH][VEC];
@@ -326,6 +329,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   const int ctx = st->row + 1;
   const int chunk = (ctx + ATT_NSPLIT - 1) / ATT_NSPLIT;
   const int j0 = s * chunk, j1 = min(ctx, j0 + chunk);
+#ifdef VX_STAMPS
+  VX_KSTAMP_ENTRY(kid, st->pass);
+#endif
 
   float qv[VEC];
 #pragma unroll
@@ -700,6 +706,7 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
   for (int j = 0; j < NVT; ++j) v[j] = lg[min(j * 256 + tid, V - 1)];
   if (st->done) return;  // uniform
   const int pass = st->pass;
+  VX_KSTAMP_ENTRY(a.kid, pass + 1);  // the pass index every later kernel of this step reads
   int* const tokens = a.tokens + (size_t)slot * a.tok_stride;
   int* const sampled = a.sampled + (size_t)slot * a.tok_stride;
   int* const argmaxes = a.argmaxes + (size_t)slot * a.tok_stride;

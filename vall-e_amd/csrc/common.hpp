@@ -12,25 +12,34 @@ extern __device__ unsigned long long g_vx_stamps[32];
   do {                                                                                                     \
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_vx_stamps[i] = wall_clock64(); \
   } while (0)
-// Per-kernel stamps of the AR decode step INSIDE the hipGraph replay (probe builds): every wave of a stamped kernel records
-// s_memrealtime (100 MHz) when it starts and when it has issued its last instruction, into ring slot `pass & 15` of the buffer
-// vx_debug_kstamps owns: [16 passes][64 kernels][1024 wave slots][entry, exit].  The host reduces entry = min / exit = max
-// over the waves of a kernel (tests/probes/ar_step_stamps.py).  The entry value is read at the top but only stored at the end,
-// so that the stamp adds no memory instruction in front of the kernel's own first loads.
+// Per-kernel stamps of the AR decode step INSIDE the hipGraph replay (probe builds).  ONE wave per kernel takes part - wave 0
+// of workgroup 0 for the entry stamp, wave 0 of the LAST workgroup for the exit stamp (mode 2) - behind a scalar branch, so every
+// other wave runs the product's instruction stream.  The entry stamp is read (s_memrealtime, 100 MHz) and stored at
+// VX_KSTAMP_ENTRY, which sits behind the kernel's own first loads: every kernel's stamp is late by about the same scalar-load
+// latency, and only DIFFERENCES between consecutive kernels' stamps are used (tests/probes/ar_step_stamps.py).
+// Ring: [16 passes][64 kernels][entry, exit] in the buffer vx_debug_kstamps owns; a pass lands in slot pass & 15.
 extern __device__ unsigned long long* g_vx_kstamps;
-#define VX_KSTAMP_BEGIN() const unsigned long long vx_t0_ = __builtin_amdgcn_s_memrealtime()
-#define VX_KSTAMP_END(kid, pass)                                                                                      \
-  do {                                                                                                                \
-    if (g_vx_kstamps != nullptr && (kid) >= 0 && (kid) < 64 && (threadIdx.x & 63) == 0) {                             \
-      const unsigned long long vx_t1_ = __builtin_amdgcn_s_memrealtime();                                             \
-      const int vx_slot_ = min((int)blockIdx.x, 255) * 4 + min((int)(threadIdx.x >> 6), 3);                           \
-      unsigned long long* vx_p_ = g_vx_kstamps + ((((size_t)((pass) & 15) * 64 + (kid)) * 1024 + vx_slot_) * 2);      \
-      vx_p_[0] = vx_t0_; vx_p_[1] = vx_t1_;                                                                            \
-    }                                                                                                                 \
+extern __device__ int g_vx_kstamps_mode;
+#define VX_KSTAMP_BEGIN() do { } while (0)
+#define VX_KSTAMP_ENTRY(kid, pass)                                                                                     \
+  do {                                                                                                                 \
+    if (blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && (kid) >= 0 && (kid) < 64) {            \
+      unsigned long long* vx_r_ = g_vx_kstamps;                                                                        \
+      if (vx_r_ != nullptr && threadIdx.x == 0) vx_r_[((size_t)((pass) & 15) * 64 + (kid)) * 2] = __builtin_amdgcn_s_memrealtime(); \
+    }                                                                                                                  \
+  } while (0)
+#define VX_KSTAMP_END(kid, pass)                                                                                       \
+  do {                                                                                                                 \
+    if (blockIdx.x == gridDim.x - 1 && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && (kid) >= 0 && (kid) < 64) { \
+      unsigned long long* vx_r_ = g_vx_kstamps;                                                                        \
+      if (vx_r_ != nullptr && g_vx_kstamps_mode == 2 && threadIdx.x == 0)                                              \
+        vx_r_[((size_t)((pass) & 15) * 64 + (kid)) * 2 + 1] = __builtin_amdgcn_s_memrealtime();                       \
+    }                                                                                                                  \
   } while (0)
 #else
 #define VX_STAMP(i) do { } while (0)
 #define VX_KSTAMP_BEGIN() do { } while (0)
+#define VX_KSTAMP_ENTRY(kid, pass) do { } while (0)
 #define VX_KSTAMP_END(kid, pass) do { } while (0)
 #endif
 
@@ -68,6 +77,11 @@ template <typename T> __device__ __forceinline__ void unpack(const uint4& r, flo
   unpack16(r, o, (T*)nullptr);
 }
 template <typename T> __device__ __forceinline__ uint4 ld16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
+typedef unsigned vx_u32x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ uint4 ld16nt(const T* p) {  // global_load_dwordx4 ... nt
+  const vx_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const vx_u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 // ---- DPP reductions (VALU cross-lane, no LDS round trip; ds_bpermute-based __shfl costs ~10x) ----
 // dpp_ctrl: 0xB1 quad_perm[1,0,3,2], 0x4E quad_perm[2,3,0,1], 0x124/0x128 row_ror:4/8,

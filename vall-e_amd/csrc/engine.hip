@@ -16,6 +16,7 @@
 #ifdef VX_STAMPS
 __device__ unsigned long long g_vx_stamps[32];
 __device__ unsigned long long* g_vx_kstamps = nullptr;
+__device__ int g_vx_kstamps_mode = 1;
 #endif
 #include "ar_kernels.hpp"
 #include "rows_kernels.hpp"
@@ -602,6 +603,9 @@ static void launch_gemv_inst(const GemvArgs& a, int grid, hipStream_t s) {
   // leading arguments = what the kernel loads from first (kernarg preload, ar_kernels.hpp)
   const float* xin = PRO == PRO_ATTN ? a.part : a.x;
   const unsigned nk = ((unsigned)a.N << 16) | (unsigned)a.K;  // N, K < 65536 (checked by the caller: K <= 4096, N <= 4 d)
+  if constexpr (std::is_same<WT, bf16>::value) {
+    if (a.nt && a.pf != nullptr) { gemv_kernel<WT, KCH, RPW, PRO, 8, true><<<grid, 256, 0, s>>>(a.W, xin, a.gamma, a.beta, nk, a); return; }
+  }
   if (a.pf != nullptr) gemv_kernel<WT, KCH, RPW, PRO, 8><<<grid, 256, 0, s>>>(a.W, xin, a.gamma, a.beta, nk, a);
   else gemv_kernel<WT, KCH, RPW, PRO, 0><<<grid, 256, 0, s>>>(a.W, xin, a.gamma, a.beta, nk, a);
 }
@@ -869,6 +873,7 @@ static int enqueue_head(vx_engine* e, hipStream_t s, const float* x = nullptr, f
   a.pro = (post && prefilled) ? PRO_COPY : PRO_LN; a.epi = EPI_LOGITS;
   a.st = st ? st : e->d_st;
   a.kid = (!prefilled && st == nullptr) ? 61 : -1;  // the decode step's head (probe builds)
+  a.nt = (pfW != nullptr && getenv("VX_AR_NT")) ? atoi(getenv("VX_AR_NT")) : 0;
   if (pfW) gemv_prefetch(a, pfW, pfN, pfK, e->bf16, e->num_cu);  // decode step: the next token's first GEMVs
   return launch_gemv(e->bf16, a, e->num_cu, s);
 }
@@ -1074,6 +1079,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
   // L2 / Infinity-Cache warm-up (GemvArgs.pf): GEMV i of the step also requests the weights of GEMV i + dist, in step order
   // [QKV_0, out_0, FFN1_0, FFN2_0, QKV_1, ..., FFN2_{L-1}, head] and wrapping into the next token's step.
   static const int pf_dist = getenv("VX_AR_PREFETCH") ? atoi(getenv("VX_AR_PREFETCH")) : 2;
+  static const int ar_nt = getenv("VX_AR_NT") ? atoi(getenv("VX_AR_NT")) : 0;  // A/B switch: non-temporal weight loads
   struct PfW { const void* W; int N, K; };
   std::vector<PfW> seq;
   for (int li = 0; li < c.num_layers; ++li) {
@@ -1104,7 +1110,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
       else { a.gamma = e->ar_l[li - 1].n2_g; a.beta = e->ar_l[li - 1].n2_b; a.xnorm_out = e->ar_xn; res = e->ar_xn; }
     }
     warm(a, 4 * li);
-    a.kid = 1 + 5 * li;
+    a.nt = ar_nt; a.kid = 1 + 5 * li;
     VXC(launch_gemv(e->bf16, a, e->num_cu, s));
 #define AD(HDV)                                                                                                                                              \
   if (hd == HDV) {                                                                                                                                           \
@@ -1123,7 +1129,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     o.W = l.out_w; o.bias = l.out_b; o.part = e->ar_part; o.y = e->ar_x; o.N = d; o.K = d; o.pro = PRO_ATTN; o.epi = EPI_RESID;
     o.res = res;
     warm(o, 4 * li + 1);
-    o.kid = 3 + 5 * li;
+    o.nt = ar_nt; o.kid = 3 + 5 * li;
     VXC(launch_gemv(e->bf16, o, e->num_cu, s));
     // f = relu(linear1(LN2(x)))
     GemvArgs f{};
@@ -1132,7 +1138,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     f.N = 4 * d; f.K = d; f.pro = PRO_LN; f.epi = EPI_RELU;
     if (post) { f.gamma = l.n1_g; f.beta = l.n1_b; f.xnorm_out = e->ar_xn; }  // x = norm1(x + sa(x)), kept in ar_xn
     warm(f, 4 * li + 2);
-    f.kid = 4 + 5 * li;
+    f.nt = ar_nt; f.kid = 4 + 5 * li;
     VXC(launch_gemv(e->bf16, f, e->num_cu, s));
     // x += linear2(f)
     GemvArgs g{};
@@ -1140,7 +1146,7 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     g.W = l.w2; g.bias = l.b2; g.x = e->ar_f; g.y = e->ar_x; g.N = d; g.K = 4 * d; g.pro = PRO_COPY; g.epi = EPI_RESID;
     if (post) g.res = e->ar_xn;  // raw sum norm1(..) + ff(..); its norm2 runs in the next layer's (or the head's) prologue
     warm(g, 4 * li + 3);
-    g.kid = 5 + 5 * li;
+    g.nt = ar_nt; g.kid = 5 + 5 * li;
     VXC(launch_gemv(e->bf16, g, e->num_cu, s));
   }
   if (pf_dist > 0) {

@@ -128,8 +128,10 @@ __global__ __launch_bounds__(256) void layernorm_rows_mx_kernel(const float* x, 
 // 64 k per stage instead of 32 and ONE v_mfma_scale_f32_32x32x64_f8f6f4 per (A fragment, W fragment) per stage:
 // 8 waves as 2 (M) x 4 (N), each 128 x 64 = 4 x 2 fragments of 32 x 32, 8 MFMAs of 64 cycles per stage = the matrix time of the
 // bf16 kernel's 32 MFMAs of 16 cycles at twice the K.
-// Lane maps (tests/probes/mx_probe.hip, exact integer data): lane (r = l & 31, h = l >> 5) holds k = 32 h .. 32 h + 31 of row r
-// in its 32 operand bytes, and the scale byte it supplies applies to exactly those 32 values.
+// Lane maps (tests/probes/mx_probe.hip, exact data with unequal block scales): lane (r = l & 31, h = l >> 5) holds, of row r,
+// k = 16 h .. 16 h + 15 in operand bytes 0-15 and k = 32 + 16 h .. 32 + 16 h + 15 in bytes 16-31; the scale byte lane (r, h)
+// supplies applies to k-block h of the row (k = 32 h .. 32 h + 31), i.e. to bytes 16 h .. 16 h + 15 of BOTH lanes of the row -
+// not to the lane's own 32 bytes (with equal scales per row the two readings cannot be told apart).
 // The MFMA is issued as (W fragment, A fragment), so the accumulator has m on the lane and n = (v&3) + 8 (v>>2) + 4 h in its
 // registers: 4 consecutive n per register quad.
 // Per stage the ring slot also carries the stage's 2 x 256 scale bytes of each operand (every wave brings 128 of the 1024 bytes
@@ -220,8 +222,8 @@ __global__ __launch_bounds__(512) void mx256_kernel(const uint8_t* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row = wn * 64 + j * 32 + r, sz = (0 - (row >> 2)) & 3;
-      w[j][0] = *reinterpret_cast<const u32x4*>(bw + row * 64 + (((2 * h) ^ sz) << 4));
-      w[j][1] = *reinterpret_cast<const u32x4*>(bw + row * 64 + (((2 * h + 1) ^ sz) << 4));
+      w[j][0] = *reinterpret_cast<const u32x4*>(bw + row * 64 + ((h ^ sz) << 4));        // k = 16 h .. +15   (block 0)
+      w[j][1] = *reinterpret_cast<const u32x4*>(bw + row * 64 + (((2 + h) ^ sz) << 4));  // k = 32 + 16 h .. (block 1)
     }
     // the scale dwords of this lane: bytes i = 0..3 are rows r + 32 i of the wave's 128-row group (mx_spos)
     sa = *reinterpret_cast<const unsigned*>(bs + wm * 128 + r * 4);
@@ -232,8 +234,8 @@ __global__ __launch_bounds__(512) void mx256_kernel(const uint8_t* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = wm * 128 + (2 * half + i) * 32 + r, sz = (0 - (row >> 2)) & 3;
-      a[i][0] = *reinterpret_cast<const u32x4*>(ba + row * 64 + (((2 * h) ^ sz) << 4));
-      a[i][1] = *reinterpret_cast<const u32x4*>(ba + row * 64 + (((2 * h + 1) ^ sz) << 4));
+      a[i][0] = *reinterpret_cast<const u32x4*>(ba + row * 64 + ((h ^ sz) << 4));
+      a[i][1] = *reinterpret_cast<const u32x4*>(ba + row * 64 + (((2 + h) ^ sz) << 4));
     }
   };
   // 4 MFMAs: A fragments 2 half .. 2 half + 1 against both W fragments (op_sel = byte of the scale dword)
