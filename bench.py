@@ -229,6 +229,8 @@ def run_rank(args) -> int:
     s_of = (lambda i: args.text_len - 7 + (i % 15)) if ragged else (lambda i: args.text_len)  # 40..54 around 47
     s_max = args.text_len + 7 if ragged else args.text_len
     sd = None
+    if Bt > 1:
+        os.environ.setdefault("VX_TIME_GEMMS", "1")  # HIP-event pairs around the NAR stages' GEMM launches (vx_get_timings)
     if dry:
         model, eng = _DryRunModel(), None
     else:
@@ -346,6 +348,21 @@ def run_rank(args) -> int:
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(step_bytes)},
         }
+        g_ms = sum(t_.get("nar_gemm_ms", 0.0) for t_ in tms)
+        g_fl = sum(t_.get("nar_gemm_flops", 0.0) for t_ in tms)
+        if Bt > 1 and g_ms > 0:
+            fp8 = args.precision == "fp8nar"
+            peak = 5000.0 if fp8 else 2500.0  # MI355X_MICROARCH.md: dense fp8 / bf16 MFMA peak, TFLOP/s
+            tf = g_fl / (g_ms * 1e-3) / 1e12
+            gemm = {"bound": "mfma", "kernel": ("NAR stage GEMMs on MXFP8 (QKV, FFN1, FFN2: mx256_kernel)" if fp8 else
+                                                  "NAR stage GEMMs in bf16 (QKV, out-projection, FFN1, FFN2: mfma256_kernel)"),
+                    "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
+                    "flops_per_launch": int(g_fl / max(1, len(tms))), "ms_per_launch": round(g_ms / max(1, len(tms)), 3),
+                    "note": "algorithmic 2 M N K of every timed GEMM / HIP-event time around the launches on the engine stream"}
+            if fp8:  # configs[4]: the fp8 GEMMs are the kernel this configuration is about; the AR step's line moves aside
+                out["ar_step_roofline"], out["roofline"] = out["roofline"], gemm
+            else:
+                out["nar_gemm_roofline"] = gemm
         if Bt == 1 and args.precision == "bf16" and not dry:
             prof, src = committed_traffic()
             if prof is not None:

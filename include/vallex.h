@@ -180,7 +180,9 @@ int vx_nar_batch_ex(vx_engine* e, int32_t n, const int64_t* const* text_nar, con
                     int64_t* const* codes_out, const int64_t* const* forced_codes, void* stream);
 
 /* Device-time of the last calls, measured with HIP events on the engine's stream:
- * out[0] prefill ms, out[1] AR decode ms, out[2] NAR ms, out[3] AR passes, out[4] graph launches. */
+ * out[0] prefill ms, out[1] AR decode ms, out[2] NAR ms, out[3] AR passes, out[4] graph launches, out[5] batched decode ms,
+ * out[6] batched graph launches; with VX_TIME_GEMMS=1 in the environment also out[7] = ms spent in the QKV / out-projection / FFN
+ * GEMM launches of the last NAR call and out[8] = their FLOPs (2 M N K each). */
 int vx_get_timings(vx_engine* e, double* out, int32_t n);
 
 /* Parity-test taps: copies an internal buffer to host memory (synchronises the engine stream).

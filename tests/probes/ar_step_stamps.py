@@ -44,66 +44,46 @@ names = ["sample+embed"] + [f"L{l}.{k}" for l in range(L) for k in ("qkv", "attn
 NK = len(names)  # 62
 
 
-def collect(mode, n_new, seed):
-    """one decode stopped after n_new tokens with the stamps armed in `mode`; the ring then holds its last 16 passes."""
-    assert lib.vx_debug_kstamps(None, mode, None) == 0
+def collect(n_new, seed):
+    """one decode stopped after n_new tokens with the stamps armed; the ring then holds its last 16 passes."""
+    assert lib.vx_debug_kstamps(None, 0, None) == 0
     torch.manual_seed(seed)
     m.inference(x, xl, y, None, top_k=10, max_new_tokens=n_new)
     t = eng.timings()
-    ring = np.zeros((16, 64, 2), dtype=np.uint64)
+    ring = np.zeros((16, 64), dtype=np.uint64)
     assert lib.vx_debug_kstamps(ring.ctypes.data_as(C.c_void_p), ring.nbytes, None) == 0
-    ring = ring[:, :NK].astype(np.int64)
-    entry, exit_ = ring[..., 0], ring[..., 1]  # (16, NK): workgroup 0's stamp / the last workgroup's end stamp (mode 2)
-    valid = (entry > 0)[..., None]
-    ok = valid.any(axis=2).all(axis=1)
+    entry = ring[:, :NK].astype(np.int64)  # (16 passes, NK kernels)
+    ok = (entry > 0).all(axis=1)
     order = [p for p in np.argsort(entry[:, 0]) if ok[p]][2:-2]  # time order; drop the oldest two and the newest two (the last step stops early)
-    return entry, exit_, order, 1e3 * t["decode_ms"] / t["launches"]
+    return entry, order, 1e3 * t["decode_ms"] / t["launches"]
 
 
 CTX = (200, 400, 600, 753)
-# mode 1: entry stamps only -> per-kernel period = next kernel's entry - this kernel's entry
-per1, hip1 = [], []
+per, hip = [], []
 for rep, n_new in enumerate(CTX):
-    entry, _, order, hip_us = collect(1, n_new, 77 + rep)
+    entry, order, hip_us = collect(n_new, 77 + rep)
     seq = np.array([np.concatenate([entry[order[i]], entry[order[i + 1]][:1]]) for i in range(len(order) - 1)])
-    per1.append(np.diff(seq, axis=1).mean(0) * 0.01)
-    hip1.append(hip_us)
-period = np.mean(per1, axis=0)  # (NK,) us
-# mode 2: entry + exit -> how a period splits into body and gap (this mode's trailing store inflates the step: ratios only)
-body2, gap2, hip2 = [], [], []
-for rep, n_new in enumerate(CTX):
-    entry, exit_, order, hip_us = collect(2, n_new, 177 + rep)
-    body2.append(np.array([(exit_[p] - entry[p]) for p in order]).mean(0) * 0.01)
-    g_in = np.array([(entry[p][1:] - exit_[p][:-1]) for p in order]).mean(0) * 0.01
-    g_step = np.mean([entry[order[i + 1]][0] - exit_[order[i]][NK - 1] for i in range(len(order) - 1)]) * 0.01
-    gap2.append(np.concatenate([g_in, [g_step]]))
-    hip2.append(hip_us)
-body2, gap2 = np.mean(body2, axis=0), np.mean(gap2, axis=0)
-share = body2 / (body2 + gap2)
-body, gap = period * share, period * (1 - share)
+    per.append(np.diff(seq, axis=1).mean(0) * 0.01)  # us: this kernel's stamp -> the next kernel's stamp
+    hip.append(hip_us)
+period = np.mean(per, axis=0)
 
 kinds = {}
 for i, n in enumerate(names):
-    k = n.split(".")[-1]
-    d = kinds.setdefault(k, dict(count=0, period_us=0.0, body_us=0.0, gap_after_us=0.0))
+    d = kinds.setdefault(n.split(".")[-1], dict(count=0, period_us=0.0))
     d["count"] += 1
-    d["period_us"] += float(period[i]); d["body_us"] += float(body[i]); d["gap_after_us"] += float(gap[i])
+    d["period_us"] += float(period[i])
 for d in kinds.values():
-    for f in ("period_us", "body_us", "gap_after_us"):
-        d[f + "_each"] = round(d[f] / d["count"], 3)
-        d[f] = round(d[f], 2)
+    d["period_us_each"] = round(d["period_us"] / d["count"], 3)
+    d["period_us"] = round(d["period_us"], 2)
 out = dict(
-    what=("AR decode step, batch 1, cfg1 (d=1024 L=12 bf16), inside the hipGraph replay: s_memrealtime stamps of the 62 kernels, mean over "
-          "passes near ctx 472 / 672 / 872 / 1025.  period = entry-to-next-entry from the entry-only build (mode 1); its split into "
-          "body (first wave's start .. last wave's end) and gap from the entry+exit build (mode 2, whose trailing stores lengthen the step)"),
-    kernels=NK, sum_period_us=round(float(period.sum()), 2), sum_body_us=round(float(body.sum()), 2), sum_gap_us=round(float(gap.sum()), 2),
-    hip_event_step_us_mode1=round(float(np.mean(hip1)), 2), hip_event_step_us_mode2=round(float(np.mean(hip2)), 2),
-    by_kind=kinds,
-    per_kernel=[dict(name=n, period_us=round(float(p_), 3), body_us=round(float(b), 3), gap_after_us=round(float(g), 3))
-                for n, p_, b, g in zip(names, period, body, gap)],
-    per_context=[dict(ctx_end=47 + 225 + c, hip_event_step_us=round(h, 2), sum_period_us=round(float(p_.sum()), 2)) for c, h, p_ in zip(CTX, hip1, per1)],
+    what=("AR decode step, batch 1, cfg1 (d=1024 L=12 bf16), inside the hipGraph replay: s_memrealtime stamps of the 62 kernels (one extra idle "
+          "workgroup per kernel records the time), mean over passes near ctx 472 / 672 / 872 / 1025.  period = this kernel's stamp to the next "
+          "kernel's stamp = the kernel's body + the boundary behind it; the periods sum to the step"),
+    kernels=NK, sum_period_us=round(float(period.sum()), 2), hip_event_step_us=round(float(np.mean(hip)), 2),
+    by_kind=kinds, per_kernel=[dict(name=n, period_us=round(float(p_), 3)) for n, p_ in zip(names, period)],
+    per_context=[dict(ctx_end=47 + 225 + c, hip_event_step_us=round(h, 2), sum_period_us=round(float(p_.sum()), 2)) for c, h, p_ in zip(CTX, hip, per)],
 )
 s = json.dumps(out, indent=1)
 if len(sys.argv) > 1:
     open(sys.argv[1], "w").write(s + "\n")
-print(json.dumps({k: out[k] for k in ("sum_period_us", "sum_body_us", "sum_gap_us", "hip_event_step_us_mode1", "hip_event_step_us_mode2", "by_kind")}))
+print(json.dumps({k: out[k] for k in ("sum_period_us", "hip_event_step_us", "by_kind")}))

@@ -65,13 +65,13 @@ template <typename WT, int KCH, int RPW, int PRO, int NPF = 0, bool NT = false>
 __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ W_, const float* __restrict__ xin,
                                                    const float* __restrict__ gamma_, const float* __restrict__ beta_,
                                                    unsigned nk, const GemvArgs a) {
-  VX_KSTAMP_BEGIN();
+  VX_KSTAMP_WG(a.kid, a.st);  // probe builds: the extra last workgroup of a stamped launch only records the time
   constexpr int VEC = Vec16<WT>::N;
   constexpr int V4 = VEC / 4;
   __shared__ __attribute__((aligned(16))) float xs[PRO == PRO_ATTN ? 1024 : 4];
   const int K = (int)(nk & 0xffffu), N = (int)(nk >> 16);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nwaves = gridDim.x * 4;
+  const int nwaves = (gridDim.x - (a.kid >= 0 ? VX_KSTAMP_EXTRA : 0)) * 4;
   const WT* __restrict__ W = reinterpret_cast<const WT*>(W_);
   int g = blockIdx.x * 4 + wave;
 
@@ -155,7 +155,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ W_, 
   // own arguments does not also wait for these
   int st_row = 0, st_pass = 0, st_trace = 0, st_done = 0, st_S = 0;
   if (st_) { st_row = st_->row; st_pass = st_->pass; st_trace = st_->trace_logits; st_done = st_->done; st_S = st_->S; }
-  VX_KSTAMP_ENTRY(a.kid, st_pass);
 
   // ---- (C) activation prologue in registers ---------------------------------------------------
   float xr[KCH][VEC];
@@ -301,7 +300,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ W_, 
 #pragma unroll
     for (int i = 0; i < NPF; ++i) asm volatile("" ::"v"(pfv[i].x), "v"(pfv[i].y), "v"(pfv[i].z), "v"(pfv[i].w));
   }
-  VX_KSTAMP_END(a.kid, st_pass);
 }
 
 // ---- single-query attention over the KV cache, split over keys (flash-decoding) -----------
@@ -314,7 +312,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
                                                           const T* __restrict__ vc, float* __restrict__ part,
                                                           const ArState* __restrict__ st, int ctx_max, float scale,
                                                           int kid) {
-  VX_KSTAMP_BEGIN();
+  VX_KSTAMP_WG(kid, st);
   constexpr int VEC = Vec16<T>::N;
   constexpr int LPK = HD / VEC;        // lanes per key: 8 (bf16) / 16 (fp32)
   constexpr int KPW = 64 / LPK;        // keys per wave-load
@@ -329,10 +327,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   const int ctx = st->row + 1;
   const int chunk = (ctx + ATT_NSPLIT - 1) / ATT_NSPLIT;
   const int j0 = s * chunk, j1 = min(ctx, j0 + chunk);
-#ifdef VX_STAMPS
-  VX_KSTAMP_ENTRY(kid, st->pass);
-#endif
-
   float qv[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; i += 4) {
@@ -403,9 +397,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     if (tid == 0) { p[0] = M; p[1] = l; }
     p[4 + tid] = o;
   }
-#ifdef VX_STAMPS
-  VX_KSTAMP_END(kid, st->pass);
-#endif
 }
 
 // ---- the same split-KV partials for head sizes other than 64 (4 .. 32: the reference's own tests run head_dim 4,
@@ -689,7 +680,6 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
 // block-level reductions, while wave 0 alone also holds all keys (NV0 per lane) for the exact top-k select.
 template <int NVT, int NV0>
 __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) {
-  VX_KSTAMP_BEGIN();
   __shared__ float s_av[4], s_sv[4], s_f[4];
   __shared__ int s_ai[4], s_si[4];
   __shared__ uint32_t cand_lds[64];
@@ -706,7 +696,9 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
   for (int j = 0; j < NVT; ++j) v[j] = lg[min(j * 256 + tid, V - 1)];
   if (st->done) return;  // uniform
   const int pass = st->pass;
-  VX_KSTAMP_ENTRY(a.kid, pass + 1);  // the pass index every later kernel of this step reads
+#ifdef VX_STAMPS
+  const unsigned long long vx_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   int* const tokens = a.tokens + (size_t)slot * a.tok_stride;
   int* const sampled = a.sampled + (size_t)slot * a.tok_stride;
   int* const argmaxes = a.argmaxes + (size_t)slot * a.tok_stride;
@@ -831,7 +823,9 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
     o.z = __fadd_rn(ev.z, __fmul_rn(alpha, pv.z)); o.w = __fadd_rn(ev.w, __fmul_rn(alpha, pv.w));
     *reinterpret_cast<float4*>(xout + c) = o;
   }
-  VX_KSTAMP_END(a.kid, pass + 1);  // the pass index every later kernel of this step reads
+#ifdef VX_STAMPS
+  VX_KSTAMP_SELF(a.kid, pass + 1, vx_t0);  // slot = the pass index every later kernel of this step reads
+#endif
 }
 
 }  // namespace vx

@@ -12,35 +12,33 @@ extern __device__ unsigned long long g_vx_stamps[32];
   do {                                                                                                     \
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_vx_stamps[i] = wall_clock64(); \
   } while (0)
-// Per-kernel stamps of the AR decode step INSIDE the hipGraph replay (probe builds).  ONE wave per kernel takes part - wave 0
-// of workgroup 0 for the entry stamp, wave 0 of the LAST workgroup for the exit stamp (mode 2) - behind a scalar branch, so every
-// other wave runs the product's instruction stream.  The entry stamp is read (s_memrealtime, 100 MHz) and stored at
-// VX_KSTAMP_ENTRY, which sits behind the kernel's own first loads: every kernel's stamp is late by about the same scalar-load
-// latency, and only DIFFERENCES between consecutive kernels' stamps are used (tests/probes/ar_step_stamps.py).
-// Ring: [16 passes][64 kernels][entry, exit] in the buffer vx_debug_kstamps owns; a pass lands in slot pass & 15.
+// Per-kernel stamps of the AR decode step INSIDE the hipGraph replay (probe builds).  The stamped kernels of the step are launched
+// with ONE EXTRA workgroup (the last) that does no work: its thread 0 records s_memrealtime (100 MHz) into ring slot
+// [pass & 15][kernel id] of the buffer vx_debug_kstamps owns and the workgroup returns (VX_KSTAMP_WG), so no wave of the real
+// computation executes anything the product does not.  The extra workgroup is dispatched last, i.e. its stamp trails the
+// kernel's start by the dispatch time of the grid (~0.5 us, about the same for every kernel): only DIFFERENCES between consecutive
+// kernels' stamps are used (tests/probes/ar_step_stamps.py).  The one-workgroup sampling kernel stamps from its own thread 0.
 extern __device__ unsigned long long* g_vx_kstamps;
-extern __device__ int g_vx_kstamps_mode;
-#define VX_KSTAMP_BEGIN() do { } while (0)
-#define VX_KSTAMP_ENTRY(kid, pass)                                                                                     \
-  do {                                                                                                                 \
-    if (blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && (kid) >= 0 && (kid) < 64) {            \
-      unsigned long long* vx_r_ = g_vx_kstamps;                                                                        \
-      if (vx_r_ != nullptr && threadIdx.x == 0) vx_r_[((size_t)((pass) & 15) * 64 + (kid)) * 2] = __builtin_amdgcn_s_memrealtime(); \
-    }                                                                                                                  \
+#define VX_KSTAMP_WG(kid, st_ptr)                                                                                  \
+  do {                                                                                                             \
+    if ((kid) >= 0 && (kid) < 64 && blockIdx.x == gridDim.x - 1) {                                                 \
+      unsigned long long* vx_r_ = g_vx_kstamps;                                                                    \
+      if (vx_r_ != nullptr && threadIdx.x == 0)                                                                    \
+        vx_r_[(size_t)(((st_ptr)->pass) & 15) * 64 + (kid)] = __builtin_amdgcn_s_memrealtime();                   \
+      return;                                                                                                      \
+    }                                                                                                              \
   } while (0)
-#define VX_KSTAMP_END(kid, pass)                                                                                       \
-  do {                                                                                                                 \
-    if (blockIdx.x == gridDim.x - 1 && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0 && (kid) >= 0 && (kid) < 64) { \
-      unsigned long long* vx_r_ = g_vx_kstamps;                                                                        \
-      if (vx_r_ != nullptr && g_vx_kstamps_mode == 2 && threadIdx.x == 0)                                              \
-        vx_r_[((size_t)((pass) & 15) * 64 + (kid)) * 2 + 1] = __builtin_amdgcn_s_memrealtime();                       \
-    }                                                                                                                  \
+#define VX_KSTAMP_SELF(kid, pass, t0)                                                                              \
+  do {                                                                                                             \
+    unsigned long long* vx_r_ = g_vx_kstamps;                                                                      \
+    if (vx_r_ != nullptr && (kid) >= 0 && (kid) < 64 && threadIdx.x == 0) vx_r_[(size_t)((pass) & 15) * 64 + (kid)] = (t0); \
   } while (0)
+constexpr int VX_KSTAMP_EXTRA = 1;  // workgroups added to a stamped launch
 #else
 #define VX_STAMP(i) do { } while (0)
-#define VX_KSTAMP_BEGIN() do { } while (0)
-#define VX_KSTAMP_ENTRY(kid, pass) do { } while (0)
-#define VX_KSTAMP_END(kid, pass) do { } while (0)
+#define VX_KSTAMP_WG(kid, st_ptr) do { } while (0)
+#define VX_KSTAMP_SELF(kid, pass, t0) do { } while (0)
+constexpr int VX_KSTAMP_EXTRA = 0;
 #endif
 
 namespace vx {

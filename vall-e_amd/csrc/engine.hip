@@ -16,7 +16,6 @@
 #ifdef VX_STAMPS
 __device__ unsigned long long g_vx_stamps[32];
 __device__ unsigned long long* g_vx_kstamps = nullptr;
-__device__ int g_vx_kstamps_mode = 1;
 #endif
 #include "ar_kernels.hpp"
 #include "rows_kernels.hpp"
@@ -159,6 +158,10 @@ struct vx_engine {
   bool prefilled = false, decoded = false;
   int n_gen = 0, stop_reason = 0, n_pass = 0, last_T = 0, last_N = 0;
   double t_prefill = 0, t_decode = 0, t_nar = 0, n_launch = 0;
+  // VX_TIME_GEMMS=1 (bench.py): HIP-event pairs around every QKV / out-projection / FFN GEMM of the NAR stages
+  std::vector<hipEvent_t> gemm_ev;
+  size_t gemm_ev_used = 0;
+  double gemm_flops = 0, t_gemm = 0, gemm_flops_done = 0;
   std::vector<void*> allocs;
 };
 
@@ -475,6 +478,7 @@ extern "C" void vx_destroy(vx_engine* e) {
   if (e->d_forced) (void)hipFree(e->d_forced);
   if (e->h_st) (void)hipHostFree(e->h_st);
   for (auto& ev : e->ev_t) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : e->gemm_ev) (void)hipEventDestroy(ev);
   for (auto& ev : e->ev_poll) if (ev) (void)hipEventDestroy(ev);
   if (e->ev_in) (void)hipEventDestroy(e->ev_in);
   if (e->ev_out) (void)hipEventDestroy(e->ev_out);
@@ -603,6 +607,7 @@ static void launch_gemv_inst(const GemvArgs& a, int grid, hipStream_t s) {
   // leading arguments = what the kernel loads from first (kernarg preload, ar_kernels.hpp)
   const float* xin = PRO == PRO_ATTN ? a.part : a.x;
   const unsigned nk = ((unsigned)a.N << 16) | (unsigned)a.K;  // N, K < 65536 (checked by the caller: K <= 4096, N <= 4 d)
+  if (a.kid >= 0) grid += VX_KSTAMP_EXTRA;  // probe builds: one extra workgroup that only records the time (common.hpp)
   if constexpr (std::is_same<WT, bf16>::value) {
     if (a.nt && a.pf != nullptr) { gemv_kernel<WT, KCH, RPW, PRO, 8, true><<<grid, 256, 0, s>>>(a.W, xin, a.gamma, a.beta, nk, a); return; }
   }
@@ -754,6 +759,27 @@ static int split_for(int K) {  // K slices of the split-K GEMMs: a multiple of t
 }
 
 static bool use_mfma(const vx_engine* e);
+static bool time_gemms() {
+  static const bool on = [] { const char* v = getenv("VX_TIME_GEMMS"); return v && atoi(v) != 0; }();
+  return on;
+}
+// event before / after a GEMM launch on the engine stream (no-op unless VX_TIME_GEMMS=1)
+static void gemm_mark(vx_engine* e, double flops) {
+  if (!time_gemms()) return;
+  if (e->gemm_ev_used == e->gemm_ev.size()) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return; e->gemm_ev.push_back(ev); }
+  (void)hipEventRecord(e->gemm_ev[e->gemm_ev_used++], e->es);
+  e->gemm_flops += flops;  // counted at the closing mark (flops > 0)
+}
+// after the stream has been synchronised: sum the pairs' elapsed times
+static void gemm_collect(vx_engine* e) {
+  e->t_gemm = 0;
+  for (size_t i = 0; i + 1 < e->gemm_ev_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->gemm_ev[i], e->gemm_ev[i + 1]) == hipSuccess) e->t_gemm += ms;
+  }
+  e->gemm_flops_done = e->gemm_flops;
+  e->gemm_ev_used = 0; e->gemm_flops = 0;
+}
 // VX_PREC_FP8_NAR: do this stage's QKV / FFN GEMMs run on MXFP8?  (NAR stages only, pre-norm, at or above the row threshold;
 // VX_MX_MIN_ROWS lowers it: the parity tests run one utterance's 1025 rows through the MXFP8 kernels)
 static bool mx_on(const vx_engine* e, int ada_stage, int M, int d) {
@@ -772,6 +798,7 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
   // adds bias + slabs to x in a fixed order.  Larger M (batched rows) has enough tiles and adds in the GEMM epilogue.
   const bool splitk = use_mfma(e) && M < 4096 && M <= e->slab_rows && d % 128 == 0 && d >= 128 && !mx_on(e, ada_stage, M, d);
   const bool mx = mx_on(e, ada_stage, M, d);
+  const bool tg = time_gemms() && ada_stage >= 0;  // NAR stages only
   const size_t sstride = (size_t)M * d;
   const int sp_d = split_for(d), sp_ff = split_for(4 * d);
   Fold pend;  // FFN2 slabs of the previous layer, folded by the next norm (pre-norm) or by the trailing fold pass
@@ -786,13 +813,17 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
     // holds it in operand precision from the previous layer's norm2 (layer 0: cast here)
     if (mx) {  // MXFP8 QKV: the LayerNorm quantises its own row, the GEMM writes bf16 q/k/v (+ V^T) for the bf16 attention
       layernorm_rows_mx_kernel<4><<<(M + 3) / 4, 256, 0, e->es>>>(e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn8, e->SHn, M, d, e->mx_ld);
+      if (tg) gemm_mark(e, 0);
       if (mx_gemm_dispatch(e->Hn8, e->SHn, e->mx_ld, l.in_q8, l.in_s8, 3 * d, l.in_b, e->QKV, nullptr, 0, M, 3 * d, d, GE_BIAS,
                            MX_OUT_BF16, e->es, (bf16*)e->VT, 2 * d, e->vt_ld))
         return fail(VX_ERR_UNSUPPORTED, "mx gemm: shape %d x %d x %d", M, 3 * d, d);
+      if (tg) gemm_mark(e, 2.0 * M * 3 * d * d);
     } else {
     if (!post) { VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d, nullptr, pend)); pend = Fold(); }
     else if (li == 0) VXC(cast_rows(e, e->X, e->Hn, (size_t)M * d));
+    if (tg) gemm_mark(e, 0);
     VXC(gemm_rows(e, e->Hn, l.in_w, l.in_b, e->QKV, M, 3 * d, d, GE_BIAS, false, use_mfma(e)));
+    if (tg) gemm_mark(e, 2.0 * M * 3 * d * d);
     }
     if (fill_cache && e->nseg > 0) {  // batched prefill: segment z -> slot z
       const size_t kvl = (size_t)2 * H * e->ctx_max * 64;  // elements per layer
@@ -806,22 +837,27 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
     }
     VXC(attn_rows(e, e->QKV, e->ATT, M, d, H, text_len));
     Fold fo;  // out-projection: x += out_proj(attn), folded into the norm that follows when split
+    if (tg && !mx) gemm_mark(e, 0);  // (MXFP8 stages: only the fp8 GEMMs are timed; the out-projection stays bf16)
     if (splitk) {
       VXC(mfma_gemm_partial((const bf16*)e->ATT, (const bf16*)l.out_w, e->slab, M, d, d, sp_d, e->es));
       fo.part = e->slab; fo.nsplit = sp_d; fo.stride = sstride; fo.bias = l.out_b;
     } else {
       VXC(gemm_rows(e, e->ATT, l.out_w, l.out_b, e->X, M, d, d, GE_RESID, true));
     }
+    if (tg && !mx) gemm_mark(e, 2.0 * M * d * d);
     if (mx) {  // MXFP8 FFN: LN2 -> fp8, FFN1's epilogue quantises its ReLU output per 32-wide block, FFN2 adds into x
       layernorm_rows_mx_kernel<4><<<(M + 3) / 4, 256, 0, e->es>>>(e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn8, e->SHn, M, d, e->mx_ld);
+      if (tg) gemm_mark(e, 0);
       if (mx_gemm_dispatch(e->Hn8, e->SHn, e->mx_ld, l.w1_q8, l.w1_s8, 4 * d, l.b1, e->FF8, e->SFF, e->mx_ld, M, 4 * d, d, GE_RELU,
                            MX_OUT_MX, e->es) ||
           mx_gemm_dispatch(e->FF8, e->SFF, e->mx_ld, l.w2_q8, l.w2_s8, d, l.b2, e->X, nullptr, 0, M, d, 4 * d, GE_RESID, MX_OUT_F32, e->es))
         return fail(VX_ERR_UNSUPPORTED, "mx gemm: FFN shapes at M=%d d=%d", M, d);
+      if (tg) gemm_mark(e, 2.0 * 2.0 * M * 4 * d * d);
       continue;
     }
     if (!post) VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn, M, d, nullptr, fo));
     else VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw1, ab1, e->Hn, M, d, e->X, fo));  // x = norm1(x + sa(x))
+    if (tg) gemm_mark(e, 0);
     VXC(gemm_rows(e, e->Hn, l.w1, l.b1, e->FF, M, 4 * d, d, GE_RELU, false));
     Fold ff;
     if (splitk) {
@@ -830,6 +866,7 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
     } else {
       VXC(gemm_rows(e, e->FF, l.w2, l.b2, e->X, M, d, 4 * d, GE_RESID, true));
     }
+    if (tg) gemm_mark(e, 2.0 * 2.0 * M * 4 * d * d);
     if (post) VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw2, ab2, e->Hn, M, d, e->X, ff));  // x = norm2(x + ff(x))
     else pend = ff;
   }
@@ -1114,12 +1151,12 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     VXC(launch_gemv(e->bf16, a, e->num_cu, s));
 #define AD(HDV)                                                                                                                                              \
   if (hd == HDV) {                                                                                                                                           \
-    if (e->bf16) attn_decode_small_kernel<bf16, HDV><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale, 2 + 5 * li); \
-    else attn_decode_small_kernel<float, HDV><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale, 2 + 5 * li);      \
+    if (e->bf16) attn_decode_small_kernel<bf16, HDV><<<H * ATT_NSPLIT + VX_KSTAMP_EXTRA, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale, 2 + 5 * li); \
+    else attn_decode_small_kernel<float, HDV><<<H * ATT_NSPLIT + VX_KSTAMP_EXTRA, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale, 2 + 5 * li);      \
   }
     if (hd == 64) {
-      if (e->bf16) attn_decode_kernel<bf16, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale, 2 + 5 * li);
-      else attn_decode_kernel<float, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale, 2 + 5 * li);
+      if (e->bf16) attn_decode_kernel<bf16, 64><<<H * ATT_NSPLIT + VX_KSTAMP_EXTRA, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, e->ctx_max, scale, 2 + 5 * li);
+      else attn_decode_kernel<float, 64><<<H * ATT_NSPLIT + VX_KSTAMP_EXTRA, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, e->ctx_max, scale, 2 + 5 * li);
     }
     AD(32) AD(16) AD(8) AD(4)
 #undef AD
@@ -1561,6 +1598,7 @@ static int nar_impl(vx_engine* e, const int64_t* text_nar, int32_t S2, const int
   float ms = 0.f;
   HIPC(hipEventElapsedTime(&ms, e->ev_t[4], e->ev_t[5]));
   e->t_nar = ms;
+  gemm_collect(e);
   e->last_T = T; e->last_N = N;
   VXC(sync_out(e, stream));
   return VX_OK;
@@ -1741,6 +1779,7 @@ static int nar_batch_impl(vx_engine* e, int32_t n, const int64_t* const* text_na
   float ms = 0.f;
   HIPC(hipEventElapsedTime(&ms, e->ev_t[4], e->ev_t[5]));
   e->t_nar = ms;
+  gemm_collect(e);
   e->last_T = (int)trows; e->last_N = (int)rows;
   VXC(sync_out(e, stream));
   return VX_OK;
@@ -1759,8 +1798,9 @@ extern "C" int vx_nar_batch_ex(vx_engine* e, int32_t n, const int64_t* const* te
 
 extern "C" int vx_get_timings(vx_engine* e, double* out, int32_t n) {
   if (!e || !out) return fail(VX_ERR_ARG, "null argument");
-  const double v[7] = {e->t_prefill, e->t_decode, e->t_nar, (double)e->n_pass, e->n_launch, e->t_bdecode, e->n_blaunch};
-  for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
+  const double v[9] = {e->t_prefill, e->t_decode, e->t_nar, (double)e->n_pass, e->n_launch, e->t_bdecode, e->n_blaunch,
+                       e->t_gemm, e->gemm_flops_done};
+  for (int i = 0; i < n && i < 9; ++i) out[i] = v[i];
   return VX_OK;
 }
 
@@ -1817,6 +1857,7 @@ extern "C" int vx_op_layernorm(int32_t prec, const float* x, const float* gamma,
 extern "C" int vx_op_gemv(int32_t prec, const void* Wp, const float* bias, const float* x, float* y, int32_t N, int32_t K,
                           int32_t relu, void* stream) {
   GemvArgs a{};
+  a.kid = -1;
   a.W = Wp; a.bias = bias; a.x = x; a.y = y; a.N = N; a.K = K;
   a.pro = PRO_COPY; a.epi = relu ? EPI_RELU : (bias ? EPI_BIAS : EPI_PLAIN);
   int dev = 0, cu = 256;

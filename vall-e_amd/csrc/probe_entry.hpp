@@ -204,17 +204,15 @@ extern "C" int vx_debug_read_stamps(unsigned long long* out, int32_t n) {
 }
 
 
-// In-graph stamps of the AR decode step (common.hpp VX_KSTAMP): dst == NULL (re)arms the device ring ([16 passes][64 kernels]
-// [entry, exit] x 8 bytes, zeroed), nbytes = mode; otherwise copies it to host memory.  dims = {16, 64, 2}.
+// In-graph stamps of the AR decode step (common.hpp VX_KSTAMP_WG): dst == NULL (re)arms the device ring ([16 passes][64 kernels]
+// x 8 bytes, zeroed); otherwise copies it to host memory.
 extern "C" int vx_debug_kstamps(void* dst, int64_t nbytes, int32_t* dims) {
 #ifdef VX_STAMPS
   static unsigned long long* ring = nullptr;
-  const size_t bytes = (size_t)16 * 64 * 2 * 8;
-  if (dims) { dims[0] = 16; dims[1] = 64; dims[2] = 2; dims[3] = 0; }
+  const size_t bytes = (size_t)16 * 64 * 8;
+  if (dims) { dims[0] = 16; dims[1] = 64; dims[2] = 0; dims[3] = 0; }
   HIPC(hipDeviceSynchronize());
   if (dst == nullptr) {
-    const int mode = nbytes == 2 ? 2 : 1;  // arming call: nbytes carries the mode (1 = entry stamps only, 2 = entry + exit)
-    HIPC(hipMemcpyToSymbol(HIP_SYMBOL(g_vx_kstamps_mode), &mode, sizeof mode));
     if (!ring) HIPC(hipMalloc((void**)&ring, bytes));
     HIPC(hipMemset(ring, 0, bytes));
     HIPC(hipMemcpyToSymbol(HIP_SYMBOL(g_vx_kstamps), &ring, sizeof ring));

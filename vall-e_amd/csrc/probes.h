@@ -23,10 +23,9 @@ int vx_debug_l2_fill(int32_t grid, int32_t threads, int32_t unroll, int64_t regi
 /* Probe builds only (csrc/build.py --stamps -> libvallex_stamps.so): phase timestamps (10 ns ticks) that workgroup 0 of the
  * last stamped kernel recorded at its VX_STAMP points.  The product library returns VX_ERR_UNSUPPORTED. */
 int vx_debug_read_stamps(unsigned long long* out, int32_t n);
-/* Stamps build only: per-kernel entry / exit times (s_memrealtime, 100 MHz) of the AR decode step inside the hipGraph replay.
- * dst == NULL arms (allocates + zeroes) the ring, with nbytes = the mode (1: entry stamps only - negligible overhead; 2: entry and
- * exit - the trailing store lengthens every kernel), otherwise the ring is copied to dst: [16 passes][64 kernel ids][entry,
- * exit] uint64; a pass lands in slot pass % 16.  dims (optional) receives {16, 64, 2, 0}. */
+/* Stamps build only: per-kernel times (s_memrealtime, 100 MHz) of the AR decode step inside the hipGraph replay, recorded by one
+ * extra, otherwise idle workgroup per kernel.  dst == NULL arms (allocates + zeroes) the ring, otherwise the ring is copied to dst:
+ * [16 passes][64 kernel ids] uint64; a pass lands in slot pass % 16. */
 int vx_debug_kstamps(void* dst, int64_t nbytes, int32_t* dims);
 
 #ifdef __cplusplus

@@ -318,10 +318,10 @@ class Engine:
         return outs
 
     def timings(self):
-        buf = (C.c_double * 7)()
-        _check(self.lib.vx_get_timings(self.h, buf, 7))
+        buf = (C.c_double * 9)()
+        _check(self.lib.vx_get_timings(self.h, buf, 9))
         return dict(prefill_ms=buf[0], decode_ms=buf[1], nar_ms=buf[2], n_pass=int(buf[3]), launches=int(buf[4]),
-                    batch_decode_ms=buf[5], batch_launches=int(buf[6]))
+                    batch_decode_ms=buf[5], batch_launches=int(buf[6]), nar_gemm_ms=buf[7], nar_gemm_flops=buf[8])
 
     def read(self, name: str, shape, dtype=torch.float32, offset_bytes: int = 0) -> torch.Tensor:
         out = torch.empty(shape, dtype=dtype)
