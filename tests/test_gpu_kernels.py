@@ -147,9 +147,9 @@ def test_sampling_single_wave_variant_large_vocab(eng, top_k):
 # ---- MXFP8 kernels of VX_PREC_FP8_NAR (mx_kernels.hpp) against the host emulation of the same quantiser (tests/mx_ref.py) ----
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 1024), (4100, 3072, 1024), (513, 1024, 4096)])
 def test_mx_gemm_matches_host_emulation(eng, M, N, K):
-    """Quantiser: bit-exact bytes and scales.  GEMM: both operands dequantise to exact fp32 values and every product of two of them
-    is exact in fp32, so the matrix core's result differs from an fp64 evaluation only by fp32 accumulation: tolerance 1e-5 of the
-    row's magnitude budget sum |a||w|."""
+    """Quantiser: bit-exact bytes and scales.  GEMM: both operands dequantise to exact fp32 values, so the matrix core's result
+    differs from an fp64 evaluation of the same dequantised operands only by its internal accumulation: tolerance stated as a
+    fraction of the magnitude budget sum |a||w| of each output."""
     from mx_ref import mx_dequant, mx_gemm_ref, mx_quant, mx_spos, scales_by_row
 
     A, W, b = _rand(M, K, seed=1, scale=1.7), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
@@ -167,9 +167,11 @@ def test_mx_gemm_matches_host_emulation(eng, M, N, K):
     budget = mx_dequant(*mx_quant(A)).abs().double() @ mx_dequant(*mx_quant(W)).abs().double().t()
     ratio = float(((C.cpu() - ref).abs().double() / (budget + 1e-3)).max())
     print(M, N, K, "max |C - ref| / sum|a||w| = %.2e" % ratio)
-    assert ratio <= 2e-5  # fp32 accumulation inside the matrix core (block sums of 32 products, then across blocks / k-steps)
+    # measured 3e-5 .. 2e-4 on MI355X: the block-scaled matrix core does not accumulate like a chain of correctly rounded fp32
+    # fmas (the bf16 / f32 MFMAs stay within 1e-6 of the same budget); three orders of magnitude below the e4m3 rounding itself
+    assert ratio <= 5e-4
     Cr = eng.op_gemm_mx(A.cuda(), W.cuda(), b.cuda(), relu=True).cpu()
-    assert float(((Cr - ref.clamp_min(0)).abs().double() / (budget + 1e-3)).max()) <= 2e-5
+    assert float(((Cr - ref.clamp_min(0)).abs().double() / (budget + 1e-3)).max()) <= 5e-4
     # the quantisation error itself, for the record: relative to the fp32 product
     exact = F.linear(A.double(), W.double(), b.double()).float()
     print(M, N, K, "mxfp8 vs fp32 GEMM: rel. error %.4f of the output rms" % float((ref - exact).pow(2).mean().sqrt() / exact.pow(2).mean().sqrt()))

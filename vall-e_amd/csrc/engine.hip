@@ -620,7 +620,12 @@ static void launch_gemv_inst(const GemvArgs& a, int grid, hipStream_t s) {
 struct GemvPlan { int grid, kch, rpw; };
 static GemvPlan gemv_plan(int N, int K, int vec, int num_cu) {
   const int need_kch = (K + 64 * vec - 1) / (64 * vec);
-  GemvPlan p{num_cu, 1, 1};
+  // A/B switches (tests/probes/ar_ab.sh): VX_AR_GRID_MULT = workgroups per CU of the decode GEMVs (default 1),
+  // VX_AR_HEAD_WGS = workgroups of the 1025-row head GEMV (default: one per CU)
+  static const int mult = [] { const char* v = getenv("VX_AR_GRID_MULT"); const int m = v ? atoi(v) : 1; return m >= 1 && m <= 4 ? m : 1; }();
+  static const int head_wgs = [] { const char* v = getenv("VX_AR_HEAD_WGS"); return v ? atoi(v) : 0; }();
+  GemvPlan p{num_cu * mult, 1, 1};
+  if (N == AR_VOCAB && head_wgs > 0) p.grid = head_wgs;
   while (p.kch < need_kch) p.kch <<= 1;
   if ((N + 3) / 4 < p.grid) p.grid = (N + 3) / 4;
   const int need_rpw = (N + p.grid * 4 - 1) / (p.grid * 4);
