@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <array>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -623,9 +624,26 @@ static GemvPlan gemv_plan(int N, int K, int vec, int num_cu) {
   // A/B switches (tests/probes/ar_ab.sh): VX_AR_GRID_MULT = workgroups per CU of the decode GEMVs (default 1),
   // VX_AR_HEAD_WGS = workgroups of the 1025-row head GEMV (default: one per CU)
   static const int mult = [] { const char* v = getenv("VX_AR_GRID_MULT"); const int m = v ? atoi(v) : 1; return m >= 1 && m <= 4 ? m : 1; }();
-  static const int head_wgs = [] { const char* v = getenv("VX_AR_HEAD_WGS"); return v ? atoi(v) : 0; }();
+  static const int head_wgs = [] { const char* v = getenv("VX_AR_HEAD_WGS"); return v ? atoi(v) : 65; }();
+  // VX_AR_WGS="NxK:wgs,NxK:wgs,...": workgroups of the GEMV with that shape (A/B runs), e.g. "1024x1024:64,1024x4096:128"
+  static const std::vector<std::array<int, 3>> wgs_tab = [] {
+    std::vector<std::array<int, 3>> t;
+    const char* v = getenv("VX_AR_WGS");
+    while (v && *v) {
+      int n = 0, k = 0, w = 0, used = 0;
+      if (sscanf(v, "%dx%d:%d%n", &n, &k, &w, &used) == 3 && w > 0) t.push_back({n, k, w});
+      else break;
+      v += used;
+      if (*v == ',') ++v;
+    }
+    return t;
+  }();
   GemvPlan p{num_cu * mult, 1, 1};
+  // the 1025-row head streams 2 MB: 65 workgroups of 4 waves x 4 rows (one pass) finish sooner than one workgroup per CU with one or
+  // two rows per wave (A/B on one box, alternating processes: 230.6 vs 236.7 us per step; 129: 234; profiles/r02_notes.md)
   if (N == AR_VOCAB && head_wgs > 0) p.grid = head_wgs;
+  for (const auto& t : wgs_tab)
+    if (t[0] == N && t[1] == K) p.grid = t[2];
   while (p.kch < need_kch) p.kch <<= 1;
   if ((N + 3) / 4 < p.grid) p.grid = (N + 3) / 4;
   const int need_rpw = (N + p.grid * 4 - 1) / (p.grid * 4);

@@ -16,23 +16,27 @@ import torch
 
 
 def read_symbol_table(path: str) -> Dict[str, int]:
-    """symbol -> id as written in the file (symbol_table.py:75-131)."""
-    sym2id: Dict[str, int] = {}
-    seen_ids = set()
-    with open(path, "r", encoding="utf-8") as f:
-        for line in f.read().strip().split("\n"):
-            fields = line.split()
-            if not fields:
+    """symbol -> id as written in a k2 symbol-table text file: whitespace-separated ``<symbol> <id>`` records, one per
+    line, blank lines ignored; both columns must be unique.  A table that never assigns id 0 gets ``<eps>`` there, which is
+    what the reference's reader leaves behind too (symbol_table.py:67-69, 75-131)."""
+    table: Dict[str, int] = {}
+    owner_of_id: Dict[int, str] = {}
+    with open(path, encoding="utf-8") as f:
+        for lineno, raw in enumerate(f, 1):
+            rec = raw.split()
+            if not rec:
                 continue
-            assert len(fields) == 2, f"Expect a line with 2 fields. Given: {len(fields)}"
-            sym, idx = fields[0], int(fields[1])
-            assert sym not in sym2id, f"Duplicated symbol {sym}"
-            assert idx not in seen_ids, f"Duplicated id {idx}"
-            sym2id[sym] = idx
-            seen_ids.add(idx)
-    if 0 not in seen_ids:  # symbol_table.py:67-69
-        sym2id["<eps>"] = 0
-    return sym2id
+            if len(rec) != 2:
+                raise ValueError(f"{path}:{lineno}: expected '<symbol> <id>', found {len(rec)} fields")
+            symbol, ident = rec[0], int(rec[1])
+            if symbol in table or ident in owner_of_id:
+                clash = symbol if symbol in table else owner_of_id[ident]
+                raise ValueError(f"{path}:{lineno}: '{symbol} {ident}' collides with the entry of '{clash}'")
+            table[symbol] = ident
+            owner_of_id[ident] = symbol
+    if 0 not in owner_of_id:
+        table.setdefault("<eps>", 0)
+    return table
 
 
 def write_symbol_table(path: str, sym2id: Dict[str, int]) -> None:
