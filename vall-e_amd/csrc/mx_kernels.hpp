@@ -579,8 +579,9 @@ static inline int mx_gemm_dispatch(const uint8_t* A, const uint8_t* SA, int lda_
     return cu > 0 ? cu : 256;
   }();
   const int grid = ntn * ntm < ncu ? ntn * ntm : ncu;
-  // VX_MX_ALG=1: the 64-byte-row ring kernel (mx256_kernel) instead of the full-line kernel (mx256w_kernel): A/B runs
-  static const int alg = [] { const char* v = getenv("VX_MX_ALG"); return v ? atoi(v) : 0; }();
+  // default: the 64-byte-row ring kernel (mx256_kernel); VX_MX_ALG=0 selects the full-line kernel (mx256w_kernel).  A/B at
+  // 117 k rows (profiles/r02_notes.md): 1335 vs 1350 TF/s - full 128-byte lines per LDS-DMA instruction buy nothing here
+  static const int alg = [] { const char* v = getenv("VX_MX_ALG"); return v ? atoi(v) : 1; }();
 #define MX(E, O)                                                                                                         \
   do {                                                                                                                  \
     static bool attr_done = false;                                                                                      \
