@@ -63,8 +63,13 @@ enum vx_flags {
   VX_FLAG_SIMPLE_ROWS = 4,  /* bf16 mode: use the scalar-FMA row kernels instead of MFMA (A/B checks) */
   VX_FLAG_PRENET = 16,      /* add_prenet=True (valle.py:96-123, 181-213): conv/BatchNorm text prenets and MLP audio
                                prenets in front of the position embeddings, fp32; batch-1 path only */
-  VX_FLAG_POST_NORM = 8     /* norm_first=False (valle.py:60, transformer.py:303-308): x = norm(x + block(x)), no final
+  VX_FLAG_POST_NORM = 8,    /* norm_first=False (valle.py:60, transformer.py:303-308): x = norm(x + block(x)), no final
                                encoder norms; batch-1 path only (max_batch must be <= 1) */
+  VX_FLAG_VALLF = 32        /* the cross-attention variant VALLF (valle.py:49-719, --model-name VALL-F): both stacks are
+                               TransformerDecoderLayers (modules/transformer.py:409-601) - causal / unmasked self-attention over
+                               the AUDIO rows only, cross-attention over the embedded text, three norms per layer.  Same entry
+                               points (VALLF.inference, valle.py:566-710, has VALLE.inference's signature); the state_dict gains
+                               layers.N.multihead_attn.* and layers.N.norm3.*.  Batch-1 path only */
 };
 
 /* Mirrors VALLE.__init__ (valle.py:727-760) / get_model (models/__init__.py:112-124). */

@@ -156,13 +156,83 @@ def run_continual(name: str, prefix_mode: int, S: int, T: int, add_prenet: bool 
                         codes=codes.numpy().astype(np.int16))
 
 
+# ---- VALL-F (valle.py:566-710).  The reference's layers run under the torch-1.13.1 TransformerDecoder loop restated in
+# oracle/ref_harness.py (the installed torch 2.10 container rejects the reference's tuple inputs): see oracle/valle_oracle.py.
+# name -> (model kwargs, S, P, top_k, temperature, sample_seed, enroll_len, ar probe steps)
+CASES_F = {
+    "vallf_mode1": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=1), 7, 14, 5, 1.0, 3, None, (0, 5)),
+    "vallf_mode0_bos": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=0, prepend_bos=True), 6, 10, 1, 1.0, None, None, (0, 5)),
+    "vallf_postnorm_prenet_mode2_q6": (dict(decoder_dim=128, nhead=2, num_decoder_layers=2, prefix_mode=2, num_quantizers=6, norm_first=False,
+                                            add_prenet=True), 8, 12, 4, 1.2, 9, 4, (0, 5)),
+    "vallf_postnorm_mode4_bos": (dict(decoder_dim=128, nhead=2, num_decoder_layers=3, prefix_mode=4, norm_first=False, prepend_bos=True), 9, 11, 3, 1.0, 13, 3, (0, 5)),
+    "vallf_prenet_scale05": (dict(decoder_dim=256, nhead=4, num_decoder_layers=4, prefix_mode=1, add_prenet=True, scale_factor=0.5), 6, 12, 4, 1.0, 11, None, (0, 9)),
+    # the geometry and option walk of the reference's own VALL-F test (valle_test.py:37-89): decoder_dim 64 / nhead 16 (head_dim 4),
+    # 4 layers, pre-norm, text (1,8), prompt (1,16,8), default sampling (top_k=-100), prepend_bos toggling, 1 / 2 / 3 quantizers
+    "vallf_reftest_mode0_bos_q1": (dict(decoder_dim=64, nhead=16, num_decoder_layers=4, prefix_mode=0, prepend_bos=True, num_quantizers=1), 8, 16, -100, 1.0, 61, 2, (0, 5)),
+    "vallf_reftest_mode1_q2": (dict(decoder_dim=64, nhead=16, num_decoder_layers=4, prefix_mode=1, num_quantizers=2), 8, 16, -100, 1.0, 62, 3, (0, 5)),
+    "vallf_reftest_mode2_bos_q3": (dict(decoder_dim=64, nhead=16, num_decoder_layers=4, prefix_mode=2, prepend_bos=True, num_quantizers=3), 8, 16, -100, 1.0, 63, 2, (0, 5)),
+    # head_dim 64 at BASELINE configs[0]'s width: the geometry the MFMA row kernels and the vectorised decode attention serve
+    "vallf_cfg0_topk10": (dict(decoder_dim=256, nhead=4, num_decoder_layers=4, prefix_mode=1), 10, 60, 10, 1.0, 1234, None, (0, 1, 80, 160)),
+}
+
+
+def run_case_f(name: str):
+    kw, S, P, top_k, temp, sseed, enroll, probes = CASES_F[name]
+    cfg = ModelConfig(model_name="VALL-F", **kw)
+    sd = synthetic_state_dict(cfg, seed=0)
+    x, x_lens, y = synthetic_inputs(S, P, 8, seed=1)
+    enroll_x_lens = None if enroll is None else torch.tensor([enroll], dtype=torch.int32)
+    ref = build_reference_model(cfg, sd)
+    ar_log, nar_log = [], {}
+    ref.ar_predict_layer.register_forward_hook(lambda m, i, o: ar_log.append(o.detach()[0].clone()))
+    if cfg.num_quantizers > 1:
+        for si, layer in enumerate(ref.nar_predict_layers):
+            layer.register_forward_hook(lambda m, i, o, si=si: nar_log.__setitem__(si, o.detach()[0, :8].clone()))
+    if sseed is not None:
+        torch.manual_seed(sseed)
+    with torch.no_grad():
+        codes = ref.inference(x, x_lens, y, enroll_x_lens=enroll_x_lens, top_k=top_k, temperature=temp)
+    n_pass = len(ar_log)
+    noise = None
+    if top_k != 1:
+        torch.manual_seed(sseed)
+        noise = torch.stack([torch.empty(1, V).exponential_(1)[0] for _ in range(n_pass)])
+    m = vo.OracleModelF(sd, cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, prefix_mode=cfg.prefix_mode, prepend_bos=cfg.prepend_bos,
+                        num_quantizers=cfg.num_quantizers, nar_scale_factor=cfg.scale_factor, norm_first=cfg.norm_first, add_prenet=cfg.add_prenet)
+    tr = {}
+    oc = vo.inference_f(m, x, x_lens, y, enroll_x_lens, top_k, temp, noise, trace=tr)
+    assert torch.equal(oc, codes), f"{name}: VALL-F oracle differs from the reference"
+    err = max(float((tr["ar_logits"][i] - ar_log[i]).abs().max()) for i in range(n_pass))
+    assert err < 1e-3
+    print(f"[{name}] reference VALL-F codes {tuple(codes.shape)}, {n_pass} passes; oracle == reference, max |logit diff| {err:.2e}", flush=True)
+    probes = [p for p in probes if p < n_pass]
+    out = dict(
+        cfg=np.array([cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, cfg.prefix_mode,
+                      int(cfg.prepend_bos), cfg.num_quantizers, int(cfg.share_embedding)], dtype=np.int32),
+        vallf=np.int32(1), weight_seed=np.int32(0), input_seed=np.int32(1), scale_factor=np.float32(cfg.scale_factor),
+        norm_first=np.int32(int(cfg.norm_first)), add_prenet=np.int32(int(cfg.add_prenet)),
+        x=x.numpy().astype(np.int16), x_lens=x_lens.numpy(), y=y.numpy().astype(np.int16),
+        enroll=np.int32(-1 if enroll is None else enroll), top_k=np.int32(top_k), temperature=np.float32(temp),
+        codes=codes.numpy().astype(np.int16), n_pass=np.int32(n_pass), ar_probe_steps=np.array(probes, dtype=np.int32),
+        ar_probe_logits=torch.stack([ar_log[p] for p in probes]).numpy(),
+    )
+    if nar_log:
+        out["nar_probe_logits"] = torch.stack([nar_log[i] for i in sorted(nar_log)]).numpy()
+    if noise is not None:
+        out["exp_noise"] = noise.numpy()
+        out["sample_seed"] = np.int32(sseed)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+
+
 CONTINUAL = {"continual_mode0": (0, 7, 41), "continual_mode1": (1, 9, 64),
              "continual_prenet_mode0": (0, 6, 37, True), "continual_prenet_mode1": (1, 8, 50, True)}
 
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
-    for c in (sys.argv[1:] or SMALL + list(CONTINUAL)):
+    for c in (sys.argv[1:] or SMALL + list(CONTINUAL) + list(CASES_F)):
         if c in CONTINUAL:
             run_continual(c, *CONTINUAL[c])
+        elif c in CASES_F:
+            run_case_f(c)
         else:
             run_case(c)

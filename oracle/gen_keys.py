@@ -25,6 +25,10 @@ CASES = {
     "q1": dict(num_quantizers=1),
     "q2_unshared": dict(num_quantizers=2, share_embedding=False),
     "scale05": dict(decoder_dim=256, nhead=4, num_decoder_layers=4, scale_factor=0.5),
+    # VALLF (valle.py:49-279 with the default decoder classes): layers gain multihead_attn.* and norm3.*
+    "vallf": dict(model_name="VALL-F"),
+    "vallf_post_norm_prenet_q6": dict(model_name="VALL-F", norm_first=False, add_prenet=True, num_quantizers=6, prepend_bos=True),
+    "vallf_scale05": dict(model_name="VALL-F", decoder_dim=256, nhead=4, num_decoder_layers=4, scale_factor=0.5),
 }
 
 if __name__ == "__main__":

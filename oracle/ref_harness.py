@@ -113,6 +113,29 @@ def load_reference():
     return _loaded
 
 
+def _torch113_decoder_forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                              memory_key_padding_mask=None):
+    """nn.TransformerDecoder.forward as of torch 1.13.1, the version the reference pins (README.md:31): a plain loop over
+    the layers and the optional final norm.  Restated here (third-party, 6 lines): the installed torch 2.10 version inspects
+    ``tgt`` for sequence length / causality and raises AttributeError on the (tensor, stage_embedding) tuple that
+    VALLF.inference passes (valle.py:626-632, 682-688), so the unmodified VALL-F path cannot run in this image."""
+    output = tgt
+    for mod in self.layers:
+        output = mod(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                     tgt_key_padding_mask=tgt_key_padding_mask, memory_key_padding_mask=memory_key_padding_mask)
+    if self.norm is not None:
+        output = self.norm(output)
+    return output
+
+
+def _use_torch113_decoder_container(model):
+    import types
+
+    for dec in (model.ar_decoder, getattr(model, "nar_decoder", None)):
+        if dec is not None:
+            dec.forward = types.MethodType(_torch113_decoder_forward, dec)
+
+
 def build_reference_model(cfg, state_dict):
     """cfg: valle_amd.config.ModelConfig.  Builds the reference VALLE via its own get_model
     (models/__init__.py:98-136), loads ``state_dict`` strictly (bin/infer.py:139-143), eval()."""
@@ -127,6 +150,8 @@ def build_reference_model(cfg, state_dict):
         num_quantizers=cfg.num_quantizers,
     )
     model = models.get_model(params)
+    if cfg.is_vallf:
+        _use_torch113_decoder_container(model)
     missing, unexpected = model.load_state_dict(state_dict, strict=True)
     assert not missing and not unexpected
     model.eval()

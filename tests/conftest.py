@@ -21,7 +21,9 @@ def golden_names(kind="inference"):
     names = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
     if kind == "continual":
         return [n for n in names if n.startswith("continual")]
-    return [n for n in names if not n.startswith("continual")]
+    if kind == "vallf":  # VALLF.inference fixtures (valle.py:566-710)
+        return [n for n in names if n.startswith("vallf")]
+    return [n for n in names if not n.startswith("continual") and not n.startswith("vallf")]
 
 
 class Golden:
@@ -33,7 +35,7 @@ class Golden:
         z = np.load(os.path.join(GOLDEN, name + ".npz"))
         self.name = name
         c = [int(v) for v in z["cfg"]]
-        self.cfg = ModelConfig(decoder_dim=c[0], nhead=c[1], num_decoder_layers=c[2], prefix_mode=c[3],
+        self.cfg = ModelConfig(model_name="VALL-F" if ("vallf" in z and int(z["vallf"])) else "VALL-E", decoder_dim=c[0], nhead=c[1], num_decoder_layers=c[2], prefix_mode=c[3],
                                prepend_bos=bool(c[4]), num_quantizers=c[5], share_embedding=bool(c[6]),
                                scale_factor=float(z["scale_factor"]) if "scale_factor" in z else 1.0,
                                norm_first=bool(int(z["norm_first"])) if "norm_first" in z else True,
@@ -65,6 +67,10 @@ class Golden:
         from oracle import valle_oracle as vo
 
         c = self.cfg
+        if c.is_vallf:
+            return vo.OracleModelF(sd if sd is not None else self.state_dict(), c.decoder_dim, c.nhead, c.num_decoder_layers,
+                                   prefix_mode=c.prefix_mode, prepend_bos=c.prepend_bos, num_quantizers=c.num_quantizers,
+                                   nar_scale_factor=c.scale_factor, norm_first=c.norm_first, add_prenet=c.add_prenet)
         return vo.OracleModel(sd if sd is not None else self.state_dict(), c.decoder_dim, c.nhead,
                               c.num_decoder_layers, c.prefix_mode, c.prepend_bos, c.num_quantizers, c.scale_factor,
                               c.norm_first, c.add_prenet)

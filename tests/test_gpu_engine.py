@@ -525,3 +525,103 @@ def test_valle_like_the_reference_test():
         params["scale_factor"] = 0.5
         params["prepend_bos"] = not params["prepend_bos"]
         params["num_quantizers"] -= 1
+
+
+# ---- VALL-F (valle.py:566-710) --------------------------------------------------------------------
+VALLF_NAMES = golden_names("vallf")
+
+
+def _model_f(g, precision, **kw):
+    import __graft_entry__ as ge
+
+    ge.build()
+    from valle_amd.models import VALLF, get_model
+
+    c = g.cfg
+    m = get_model(dict(model_name="VALL-F", decoder_dim=c.decoder_dim, nhead=c.nhead, num_decoder_layers=c.num_decoder_layers,
+                       scale_factor=c.scale_factor, norm_first=c.norm_first, add_prenet=c.add_prenet, prefix_mode=c.prefix_mode,
+                       share_embedding=c.share_embedding, prepend_bos=c.prepend_bos, num_quantizers=c.num_quantizers,
+                       precision=precision, max_text=128, max_audio=1280))
+    assert isinstance(m, VALLF)
+    m.print_eos = False
+    for k, v in kw.items():
+        m.engine_opts[k] = v
+    m.load_state_dict(g.state_dict())
+    return m.to("cuda:0").eval()
+
+
+@pytest.mark.parametrize("name", VALLF_NAMES)
+def test_vallf_fp32_engine_reproduces_reference_codes(name):
+    """The fixtures are the reference's own VALLF layers run under the torch-1.13.1 decoder loop (oracle/ref_harness.py); the
+    fp32 engine must reproduce their codes bit for bit: KV-cached causal self-attention over the audio rows, cross-attention
+    over the text memory projected once, three norms per layer, pre- and post-norm, prenets, prefix modes 0/1/2/4."""
+    g = Golden(name)
+    m = _model_f(g, "fp32", trace_logits=True)
+    codes = _run(m, g)
+    assert codes.shape == g.codes.shape
+    assert torch.equal(codes, g.codes)
+    e = m.engine()
+    for step, ref in zip(g.ar_probe_steps, g.ar_probe_logits):
+        got = e.read("ar_logits", (1025,), offset_bytes=step * 1025 * 4)
+        assert (got - ref).abs().max() <= 2e-4, step
+    if g.nar_probe_logits is not None:
+        got = e.read("nar_logits", (8, 1024))
+        assert (got - g.nar_probe_logits[-1]).abs().max() <= 2e-3
+
+
+def test_vallf_graph_and_eager_steps_agree():
+    g = Golden("vallf_mode1")
+    a = _run(_model_f(g, "fp32"), g)
+    b = _run(_model_f(g, "fp32", no_graph=True), g)
+    assert torch.equal(a, b) and torch.equal(a, g.codes)
+
+
+@pytest.mark.parametrize("name,simple", [("vallf_cfg0_topk10", False), ("vallf_cfg0_topk10", True), ("vallf_postnorm_mode4_bos", False),
+                                         ("vallf_reftest_mode2_bos_q3", False)])
+def test_vallf_bf16_engine_teacher_forced(name, simple):
+    """bf16 VALL-F engine, teacher-forced with the reference's tokens: AR logits within 3 % of a row's scale and argmax equal
+    wherever the reference's margin exceeds twice that; NAR stages fed the reference's earlier codes, per-stage agreement."""
+    from oracle import valle_oracle as vo
+
+    g = Golden(name)
+    m = _model_f(g, "bf16", trace_logits=True, simple_rows=simple)
+    e = m.engine()
+    Q = g.cfg.num_quantizers
+    text, prompts = g.x[0], g.y[0, :, :Q].contiguous()
+    forced = g.codes[0, :, 0].contiguous()
+    e.ar_prefill(text, prompts[:, 0].contiguous())
+    e.ar_decode(top_k=g.top_k, temperature=g.temperature, exp_noise=g.exp_noise, forced=forced)
+    toks, reason, n_pass = e.ar_result()
+    assert torch.equal(toks, forced) and n_pass == forced.numel() + 1
+    tr = {}
+    # fp32 oracle, teacher-forced with the same tokens (AR part only: a one-quantizer view of the same weights)
+    c = g.cfg
+    m1 = vo.OracleModelF(g.state_dict(), c.decoder_dim, c.nhead, c.num_decoder_layers, prefix_mode=c.prefix_mode, prepend_bos=c.prepend_bos,
+                         num_quantizers=1, nar_scale_factor=c.scale_factor, norm_first=c.norm_first, add_prenet=c.add_prenet)
+    vo.inference_f(m1, g.x, g.x_lens, g.y, g.enroll_x_lens, g.top_k, g.temperature, g.exp_noise, trace=tr, forced=forced)
+    got_all = e.read("ar_logits", (n_pass, 1025))
+    worst = 0.0
+    for s in range(0, n_pass, 7):
+        ref = tr["ar_logits"][s]
+        tol = 0.03 * float(ref.abs().max())
+        err = float((got_all[s] - ref).abs().max())
+        worst = max(worst, err / float(ref.abs().max()))
+        assert err <= tol, (s, err, tol)
+        top2 = ref.topk(2)[0]
+        if float(top2[0] - top2[1]) > 2 * tol:
+            assert int(got_all[s].argmax()) == int(ref.argmax())
+    if Q > 1:
+        text_nar = text if c.prefix_mode not in (2, 4) else torch.cat([text[:1], text[int(g.enroll_x_lens.max()) - 1:]])
+        codes = e.nar(text_nar, prompts, forced, forced_codes=g.codes[0]).cpu()
+        per_stage = (codes[:, 1:] == g.codes[0, :, 1:]).float().mean(0)
+        print(name, "simple" if simple else "mfma", "AR worst rel err %.4f" % worst, "NAR agreement per stage", [round(float(v), 4) for v in per_stage])
+        assert float(per_stage.min()) >= 0.90, per_stage
+
+
+def test_vallf_has_no_continual_and_no_batch():
+    g = Golden("vallf_mode1")
+    m = _model_f(g, "fp32")
+    with pytest.raises(AttributeError):
+        m.continual(g.x, g.x_lens, g.y)
+    with pytest.raises(NotImplementedError):
+        m.inference_batch([(g.x, g.x_lens, g.y)])

@@ -78,3 +78,20 @@ def test_continual_oracle_matches_reference(name):
     """VALLE.continual (valle.py:1139-1238), SURVEY.md §8(f) rank 1."""
     g = Golden(name)
     assert torch.equal(vo.continual(g.oracle(), g.x, g.x_lens, g.y), g.codes)
+
+
+@pytest.mark.parametrize("name", golden_names("vallf"))
+def test_vallf_oracle_matches_reference(name):
+    """VALLF.inference (valle.py:566-710), SURVEY.md §8(f) rank 4.  The fixtures come from the reference's own layers under the
+    torch-1.13.1 TransformerDecoder loop restated in oracle/ref_harness.py (see oracle/valle_oracle.py: the installed torch 2.10
+    container rejects the reference's tuple inputs)."""
+    g = Golden(name)
+    assert g.cfg.is_vallf
+    tr = {}
+    codes = vo.inference_f(g.oracle(), g.x, g.x_lens, g.y, g.enroll_x_lens, g.top_k, g.temperature, g.exp_noise, trace=tr)
+    assert torch.equal(codes, g.codes)
+    for step, ref in zip(g.ar_probe_steps, g.ar_probe_logits):
+        assert (tr["ar_logits"][step] - ref).abs().max() <= 1e-5
+    if g.nar_probe_logits is not None:
+        for i, ref in enumerate(g.nar_probe_logits):
+            assert (tr["nar_logits"][i][:8] - ref).abs().max() <= 2e-4, i

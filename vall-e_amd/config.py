@@ -46,6 +46,11 @@ class ModelConfig:
     prepend_bos: bool = False
     num_quantizers: int = 8
 
+    @property
+    def is_vallf(self) -> bool:
+        """models/__init__.py:99: the cross-attention variant is selected by name."""
+        return self.model_name.lower() in ("vall-f", "vallf")
+
     # derived (valle.py:83, 231-241)
     @property
     def nar_dim(self) -> int:

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ W_, 
   // decode state (scalar loads, used by the epilogues only): after the warm-up loads, so that the wait for the warm-up's
   // own arguments does not also wait for these
   int st_row = 0, st_pass = 0, st_trace = 0, st_done = 0, st_S = 0;
-  if (st_) { st_row = st_->row; st_pass = st_->pass; st_trace = st_->trace_logits; st_done = st_->done; st_S = st_->S; }
+  if (st_) { st_row = st_->row; st_pass = st_->pass; st_trace = st_->trace_logits; st_done = st_->done; st_S = st_->kv_text; }
 
   // ---- (C) activation prologue in registers ---------------------------------------------------
   float xr[KCH][VEC];
@@ -311,7 +311,7 @@ template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ q, const T* __restrict__ kc,
                                                           const T* __restrict__ vc, float* __restrict__ part,
                                                           const ArState* __restrict__ st, int ctx_max, float scale,
-                                                          int kid) {
+                                                          int kid, int fixed_ctx = 0) {
   VX_KSTAMP_WG(kid, st);
   constexpr int VEC = Vec16<T>::N;
   constexpr int LPK = HD / VEC;        // lanes per key: 8 (bf16) / 16 (fp32)
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   const int h = blockIdx.x / ATT_NSPLIT, s = blockIdx.x - h * ATT_NSPLIT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPK, grp = lane / LPK;
-  const int ctx = st->row + 1;
+  const int ctx = fixed_ctx > 0 ? fixed_ctx : st->row + 1;  // fixed_ctx: cross-attention over the cached text memory (VALL-F)
   const int chunk = (ctx + ATT_NSPLIT - 1) / ATT_NSPLIT;
   const int j0 = s * chunk, j1 = min(ctx, j0 + chunk);
   float qv[VEC];
@@ -406,12 +406,12 @@ template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_decode_small_kernel(const float* __restrict__ q, const T* __restrict__ kc,
                                                                 const T* __restrict__ vc, float* __restrict__ part,
                                                                 const ArState* __restrict__ st, int ctx_max, float scale,
-                                                                int kid) {
+                                                                int kid, int fixed_ctx = 0) {
   __shared__ float sm_m[256], sm_l[256];
   __shared__ float sm_o[256][HD + 1];
   const int h = blockIdx.x / ATT_NSPLIT, s = blockIdx.x - h * ATT_NSPLIT;
   const int tid = threadIdx.x;
-  const int ctx = st->row + 1;
+  const int ctx = fixed_ctx > 0 ? fixed_ctx : st->row + 1;
   const int chunk = (ctx + ATT_NSPLIT - 1) / ATT_NSPLIT;
   const int j0 = s * chunk, j1 = min(ctx, j0 + chunk);
   float qv[HD], o[HD];
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
   }
   if (!go) return;
   // x = E[tok] * 1.0 + alpha * pe[audio position] (valle.py:1013-1015; embedding.py:93-97)
-  const int apos = row - S;
+  const int apos = row - st->kv_text;
   for (int c = lane * 4; c < a.d; c += 256) {
     const float4 ev = *reinterpret_cast<const float4*>(a.emb + (size_t)tok * a.d + c);
     const float4 pv = *reinterpret_cast<const float4*>(a.pe + (size_t)apos * a.d + c);
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
     if (go) { st->row = row; st->pass = pass + 1; }
   }
   if (!go) return;
-  const int apos = row - S;
+  const int apos = row - st->kv_text;
   for (int c = tid * 4; c < a.d; c += 1024) {
     const float4 ev = *reinterpret_cast<const float4*>(a.emb + (size_t)tok * a.d + c);
     const float4 pv = *reinterpret_cast<const float4*>(a.pe + (size_t)apos * a.d + c);

@@ -236,7 +236,8 @@ struct ArState {
   unsigned long long seed;
   const long long* forced;
   int32_t trace_logits;
-  int32_t pad_;
+  int32_t kv_text;    // rows in front of the audio sub-sequence in the KV cache: S for VALL-E (text rows are cached), 0 for VALL-F
+                      // (the text is cross-attention memory); audio position of KV row r = r - kv_text (valle.py:1013-1016)
 };
 
 }  // namespace vx

@@ -83,6 +83,9 @@ struct LayerW {
   const void *in_w, *out_w, *w1, *w2;
   const float *in_b, *out_b, *b1, *b2;
   const float *n1_g, *n1_b, *n2_g, *n2_b;
+  // VALL-F (TransformerDecoderLayer): cross-attention over the text memory and the third norm
+  const void *cin_w = nullptr, *cout_w = nullptr;
+  const float *cin_b = nullptr, *cout_b = nullptr, *n3_g = nullptr, *n3_b = nullptr;
 };
 
 constexpr int POLL_CHUNK = 32;
@@ -93,6 +96,10 @@ struct vx_engine {
   bool fp8nar = false;  // VX_PREC_FP8_NAR: bf16 everywhere + MXFP8 QKV / FFN GEMMs in the NAR stages at >= 4096 rows
   uint8_t *Hn8 = nullptr, *SHn = nullptr, *FF8 = nullptr, *SFF = nullptr;  // MXFP8 row operands and their scales (ld = mx_ld)
   int mx_ld = 0;
+  bool vallf = false;  // VX_FLAG_VALLF: decoder layers with cross-attention over the text (valle.py:49-719)
+  int npl = 2;         // norms per layer: 2 (encoder layers) / 3 (decoder layers)
+  void *xkv_ar = nullptr, *xkv_nar = nullptr;  // VALL-F: per-layer K / V of the text memory, [layer][K|V][head][max_text][hd]
+  int mem_len = 0;     // text rows of the current utterance's AR memory
   bool hd64 = true;  // head_dim 64 in both stacks: the MFMA row kernels and the batched decode apply
   size_t esz = 4;  // bytes per matrix / KV / GEMM-operand element
   int num_cu = 256;
@@ -203,6 +210,7 @@ static bool is_mx_key(const std::string& k) {  // the NAR stack's QKV / FFN matr
 // The reference's state_dict layout (valle.py:85-259); mirrored by valle_amd/weights.py.
 static void add_encoder_keys(vx_engine* e, const std::string& pre, int d, int L, bool adaptive) {
   const bool post = e->cfg.flags & VX_FLAG_POST_NORM;  // norm=... if norm_first else None (valle.py:151, 242-246)
+  const bool cross = e->cfg.flags & VX_FLAG_VALLF;     // TransformerDecoderLayer (modules/transformer.py:412-500)
   auto add = [&](const std::string& k, std::vector<int64_t> s) {
     Tensor t; t.shape = s; t.numel = 1; for (auto v : s) t.numel *= (size_t)v;
     t.low = e->bf16 && is_matrix_key(k);
@@ -220,9 +228,14 @@ static void add_encoder_keys(vx_engine* e, const std::string& pre, int d, int L,
     const std::string p = pre + ".layers." + std::to_string(i);
     add(p + ".self_attn.in_proj_weight", {3 * d, d}); add(p + ".self_attn.in_proj_bias", {3 * d});
     add(p + ".self_attn.out_proj.weight", {d, d}); add(p + ".self_attn.out_proj.bias", {d});
+    if (cross) {
+      add(p + ".multihead_attn.in_proj_weight", {3 * d, d}); add(p + ".multihead_attn.in_proj_bias", {3 * d});
+      add(p + ".multihead_attn.out_proj.weight", {d, d}); add(p + ".multihead_attn.out_proj.bias", {d});
+    }
     add(p + ".linear1.weight", {4 * d, d}); add(p + ".linear1.bias", {4 * d});
     add(p + ".linear2.weight", {d, 4 * d}); add(p + ".linear2.bias", {d});
     norm(p + ".norm1"); norm(p + ".norm2");
+    if (cross) norm(p + ".norm3");
   }
   if (!post) norm(pre + ".norm");
 }
@@ -309,8 +322,9 @@ extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   if (c.precision == VX_PREC_FP8_NAR && (c.num_quantizers < 2 || c.nar_d_model % 256 || c.nar_d_model / c.nar_nhead != 64 ||
                                          (c.flags & (VX_FLAG_POST_NORM | VX_FLAG_PRENET | VX_FLAG_SIMPLE_ROWS))))
     return fail(VX_ERR_UNSUPPORTED, "VX_PREC_FP8_NAR needs a pre-norm NAR stack without prenets, head_dim 64 and nar_d_model % 256 == 0");
-  if ((c.flags & (VX_FLAG_POST_NORM | VX_FLAG_PRENET)) && c.max_batch > 1)
-    return fail(VX_ERR_UNSUPPORTED, "post-norm / prenet models run on the batch-1 path only");
+  if ((c.flags & (VX_FLAG_POST_NORM | VX_FLAG_PRENET | VX_FLAG_VALLF)) && c.max_batch > 1)
+    return fail(VX_ERR_UNSUPPORTED, "post-norm / prenet / VALL-F models run on the batch-1 path only");
+  if ((c.flags & VX_FLAG_VALLF) && c.precision == VX_PREC_FP8_NAR) return fail(VX_ERR_UNSUPPORTED, "VX_PREC_FP8_NAR is built for VALL-E only");
   if (c.max_batch < 0 || c.max_batch > BMAX) return fail(VX_ERR_ARG, "max_batch must be 0..%d", BMAX);
   if (c.max_batch > 1 && (c.precision == VX_PREC_F32 || c.d_model % 128))
     return fail(VX_ERR_UNSUPPORTED, "batched decode needs bf16 precision and d_model % 128 == 0");
@@ -335,6 +349,8 @@ static int create_body(vx_engine* e) {
   e->bf16 = c.precision != VX_PREC_F32;
   e->fp8nar = c.precision == VX_PREC_FP8_NAR;
   e->hd64 = hd64;
+  e->vallf = c.flags & VX_FLAG_VALLF;
+  e->npl = e->vallf ? 3 : 2;
   e->esz = e->bf16 ? 2 : 4;
   hipDeviceProp_t prop;
   HIPC(hipGetDeviceProperties(&prop, c.device));
@@ -452,7 +468,11 @@ static int create_body(vx_engine* e) {
     HIPC(hipMemsetAsync(e->bst, 0, (size_t)BMAX * sizeof(ArState), e->es));
   }
   if (c.num_quantizers > 1)
-    VXC(dalloc_t(e, &e->ada, (size_t)(c.num_quantizers - 1) * (2 * c.nar_num_layers + 1) * 2 * dn));
+    VXC(dalloc_t(e, &e->ada, (size_t)(c.num_quantizers - 1) * (e->npl * c.nar_num_layers + 1) * 2 * dn));
+  if (e->vallf) {  // K / V of the text memory per layer, in the decode-cache layout with max_text rows per head
+    VXC(dalloc(e, &e->xkv_ar, (size_t)c.num_layers * 2 * d * c.max_text * e->esz));
+    if (c.num_quantizers > 1) VXC(dalloc(e, &e->xkv_nar, (size_t)c.nar_num_layers * 2 * dn * c.max_text * e->esz));
+  }
   // weights
   for (auto& k : e->keys) {
     Tensor& t = e->w[k];
@@ -546,12 +566,18 @@ static void fill_layers(vx_engine* e, const std::string& pre, int L, bool adapti
     const std::string s = adaptive ? ".norm" : "";
     l.n1_g = W<float>(e, p + ".norm1" + s + ".weight"); l.n1_b = W<float>(e, p + ".norm1" + s + ".bias");
     l.n2_g = W<float>(e, p + ".norm2" + s + ".weight"); l.n2_b = W<float>(e, p + ".norm2" + s + ".bias");
+    if (e->vallf) {
+      l.cin_w = W<void>(e, p + ".multihead_attn.in_proj_weight"); l.cin_b = W<float>(e, p + ".multihead_attn.in_proj_bias");
+      l.cout_w = W<void>(e, p + ".multihead_attn.out_proj.weight"); l.cout_b = W<float>(e, p + ".multihead_attn.out_proj.bias");
+      l.n3_g = W<float>(e, p + ".norm3" + s + ".weight"); l.n3_b = W<float>(e, p + ".norm3" + s + ".bias");
+    }
   }
 }
 
-// AdaLN vectors: index (stage, site) -> 2*dn floats [w | b]; site = 2*layer + {0,1}, last = final norm
+// AdaLN vectors: index (stage, site) -> 2*dn floats [w | b]; site = npl*layer + {0 .. npl-1} (npl = 2 norms per encoder layer,
+// 3 per VALL-F decoder layer), last = final norm
 static float* ada_vec(vx_engine* e, int stage, int site) {
-  const int sites = 2 * e->cfg.nar_num_layers + 1;
+  const int sites = e->npl * e->cfg.nar_num_layers + 1;
   return e->ada + ((size_t)stage * sites + site) * 2 * e->cfg.nar_d_model;
 }
 
@@ -576,10 +602,11 @@ extern "C" int vx_finalize_weights(vx_engine* e) {
     const int dn = c.nar_d_model, Ln = c.nar_num_layers;
     for (int s = 0; s < c.num_quantizers - 1; ++s) {
       const float* emb = W<float>(e, "nar_stage_embeddings." + std::to_string(s) + ".word_embeddings.weight");
-      const int nsite = 2 * Ln + ((c.flags & VX_FLAG_POST_NORM) ? 0 : 1);  // post-norm: no final AdaLN
+      const int npl = e->npl;
+      const int nsite = npl * Ln + ((c.flags & VX_FLAG_POST_NORM) ? 0 : 1);  // post-norm: no final AdaLN
       for (int site = 0; site < nsite; ++site) {
-        std::string p = site == 2 * Ln ? std::string("nar_decoder.norm")
-                                       : "nar_decoder.layers." + std::to_string(site / 2) + (site % 2 ? ".norm2" : ".norm1");
+        std::string p = site == npl * Ln ? std::string("nar_decoder.norm")
+                                         : "nar_decoder.layers." + std::to_string(site / npl) + ".norm" + std::to_string(site % npl + 1);
         project_vec_kernel<<<(2 * dn + 3) / 4, 256, 0, e->es>>>(W<float>(e, p + ".project_layer.weight"),
                                                                 W<float>(e, p + ".project_layer.bias"), emb,
                                                                 ada_vec(e, s, site), 2 * dn, dn);
@@ -899,6 +926,85 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
   return VX_OK;
 }
 
+// ---- VALL-F (valle.py:49-719): stacks of TransformerDecoderLayers (modules/transformer.py:409-601) -------------------------
+// Text memory -> per-layer K / V in the decode-cache layout (nhead, max_text, hd).  `mem` = S rows of the embedded text in
+// operand precision (e->Hn).  The packed cross in_proj is applied whole (the q third of the result is unused): every output
+// element is its own dot product, so rows [d, 3d) equal linear(mem, w[d:], b[d:]) of torch's _in_projection_packed.
+static int memory_kv(vx_engine* e, const std::vector<LayerW>& layers, void* xkv, int S, int d, int H) {
+  const int hd = d / H;
+  const size_t per_layer = (size_t)2 * d * e->cfg.max_text * e->esz;
+  for (size_t li = 0; li < layers.size(); ++li) {
+    VXC(gemm_rows(e, e->Hn, layers[li].cin_w, layers[li].cin_b, e->QKV, S, 3 * d, d, GE_BIAS, false, false));
+    char* kc = (char*)xkv + li * per_layer;
+    char* vc = kc + per_layer / 2;
+    if (e->bf16) kv_scatter_kernel<bf16><<<S, 256, 0, e->es>>>((const bf16*)e->QKV, (bf16*)kc, (bf16*)vc, S, d, hd, e->cfg.max_text);
+    else kv_scatter_kernel<float><<<S, 256, 0, e->es>>>((const float*)e->QKV, (float*)kc, (float*)vc, S, d, hd, e->cfg.max_text);
+  }
+  HIPC(hipGetLastError());
+  return VX_OK;
+}
+
+static int cross_attn_rows(vx_engine* e, const void* q, const void* kc, const void* vc, void* out, int M, int d, int H, int Sk) {
+  const int hd = d / H;
+  const float scale = 1.0f / sqrtf((float)hd);
+  dim3 grid((M + 63) / 64, H);
+#define CA(HDV)                                                                                                                  \
+  if (hd == HDV) {                                                                                                               \
+    if (e->bf16) cross_attn_rows_kernel<bf16, HDV><<<grid, 256, 0, e->es>>>((const bf16*)q, d, (const bf16*)kc, (const bf16*)vc, \
+                                                                            e->cfg.max_text, (bf16*)out, d, M, Sk, scale);       \
+    else cross_attn_rows_kernel<float, HDV><<<grid, 256, 0, e->es>>>((const float*)q, d, (const float*)kc, (const float*)vc,     \
+                                                                     e->cfg.max_text, (float*)out, d, M, Sk, scale);             \
+    return VX_OK;                                                                                                                \
+  }
+  CA(64) CA(32) CA(16) CA(8) CA(4)
+#undef CA
+  return fail(VX_ERR_UNSUPPORTED, "cross-attention: head_dim %d", hd);
+}
+
+// One decoder stack over the M audio rows held in e->X (valle.py:626-632 AR with text_len = 0: causal; valle.py:682-688 NAR
+// with text_len < 0: no mask).  Memory K / V of layer li at xkv + li * per_layer, Sk text rows.  Plain epilogue adds (no
+// split-K slabs): this variant is built for parity, not tuned.
+static int run_stack_f(vx_engine* e, const std::vector<LayerW>& layers, int M, int d, int H, int text_len, int ada_stage,
+                       bool fill_cache, const void* xkv, int Sk) {
+  const bool post = e->cfg.flags & VX_FLAG_POST_NORM;
+  const int hd = d / H;
+  const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd * e->esz;
+  const size_t per_layer = (size_t)2 * d * e->cfg.max_text * e->esz;
+  for (size_t li = 0; li < layers.size(); ++li) {
+    const LayerW& l = layers[li];
+    const float *aw[3] = {nullptr, nullptr, nullptr}, *ab[3] = {nullptr, nullptr, nullptr};
+    if (ada_stage >= 0)
+      for (int k = 0; k < 3; ++k) { aw[k] = ada_vec(e, ada_stage, 3 * (int)li + k); ab[k] = aw[k] + d; }
+    // self-attention: pre-norm x += sa(norm1(x)) (transformer.py:536-539); post-norm x = norm1(x + sa(x)) (547-550)
+    if (!post) VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw[0], ab[0], e->Hn, M, d));
+    else if (li == 0) VXC(cast_rows(e, e->X, e->Hn, (size_t)M * d));
+    VXC(gemm_rows(e, e->Hn, l.in_w, l.in_b, e->QKV, M, 3 * d, d, GE_BIAS, false, use_mfma(e)));
+    if (fill_cache) {
+      char* kc = (char*)e->kv + li * kv_layer;
+      char* vc = kc + kv_layer / 2;
+      if (e->bf16) kv_scatter_kernel<bf16><<<M, 256, 0, e->es>>>((const bf16*)e->QKV, (bf16*)kc, (bf16*)vc, M, d, hd, e->ctx_max);
+      else kv_scatter_kernel<float><<<M, 256, 0, e->es>>>((const float*)e->QKV, (float*)kc, (float*)vc, M, d, hd, e->ctx_max);
+    }
+    VXC(attn_rows(e, e->QKV, e->ATT, M, d, H, text_len));
+    VXC(gemm_rows(e, e->ATT, l.out_w, l.out_b, e->X, M, d, d, GE_RESID, true));
+    // cross-attention over the text: x += mha(norm2(x), memory) (540-545); post-norm x = norm2(x + mha(x, memory)) (551-557)
+    if (!post) VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw[1], ab[1], e->Hn, M, d));
+    else VXC(ln_rows(e, e->X, l.n1_g, l.n1_b, aw[0], ab[0], e->Hn, M, d, e->X));
+    VXC(gemm_rows(e, e->Hn, l.cin_w, l.cin_b, e->QKV, M, d, d, GE_BIAS, false, false));  // q = rows [0, d) of the packed in_proj
+    const char* xk = (const char*)xkv + li * per_layer;
+    VXC(cross_attn_rows(e, e->QKV, xk, xk + per_layer / 2, e->ATT, M, d, H, Sk));
+    VXC(gemm_rows(e, e->ATT, l.cout_w, l.cout_b, e->X, M, d, d, GE_RESID, true));
+    // feed-forward: x += ff(norm3(x)) (546); post-norm x = norm3(x + ff(x)) (558)
+    if (!post) VXC(ln_rows(e, e->X, l.n3_g, l.n3_b, aw[2], ab[2], e->Hn, M, d));
+    else VXC(ln_rows(e, e->X, l.n2_g, l.n2_b, aw[1], ab[1], e->Hn, M, d, e->X));
+    VXC(gemm_rows(e, e->Hn, l.w1, l.b1, e->FF, M, 4 * d, d, GE_RELU, false));
+    VXC(gemm_rows(e, e->FF, l.w2, l.b2, e->X, M, d, 4 * d, GE_RESID, true));
+    if (post) VXC(ln_rows(e, e->X, l.n3_g, l.n3_b, aw[2], ab[2], e->Hn, M, d, e->X));
+  }
+  HIPC(hipGetLastError());
+  return VX_OK;
+}
+
 static int sync_in(vx_engine* e, void* stream) {
   hipStream_t cs = (hipStream_t)stream;
   if (cs == e->es) return VX_OK;
@@ -926,8 +1032,9 @@ static int enqueue_head(vx_engine* e, hipStream_t s, const float* x = nullptr, f
   a.W = W<void>(e, "ar_predict_layer.weight");
   a.bias = nullptr;
   a.x = x ? x : e->ar_x;
-  a.gamma = post ? e->ar_l.back().n2_g : W<float>(e, "ar_decoder.norm.weight");
-  a.beta = post ? e->ar_l.back().n2_b : W<float>(e, "ar_decoder.norm.bias");
+  // post-norm: the last layer's closing norm (norm2 of an encoder layer, norm3 of a VALL-F decoder layer)
+  a.gamma = post ? (e->vallf ? e->ar_l.back().n3_g : e->ar_l.back().n2_g) : W<float>(e, "ar_decoder.norm.weight");
+  a.beta = post ? (e->vallf ? e->ar_l.back().n3_b : e->ar_l.back().n2_b) : W<float>(e, "ar_decoder.norm.bias");
   a.y = logits ? logits : e->ar_logits;
   a.N = AR_VOCAB; a.K = c.d_model;
   a.pro = (post && prefilled) ? PRO_COPY : PRO_LN; a.epi = EPI_LOGITS;
@@ -945,7 +1052,8 @@ static int prefill_impl(vx_engine* e, int slot, const int64_t* text, int32_t S, 
   if (!e->finalized) return fail(VX_ERR_STATE, "weights not finalized");
   if (S <= 0 || P < 0) return fail(VX_ERR_ARG, "S must be > 0 (valle.py:991), P >= 0");
   const vx_config& c = e->cfg;
-  const int bos = c.prepend_bos ? 1 : 0, A = bos + P, M = S + A, d = c.d_model;
+  const bool vf = e->vallf;  // VALL-F: the stack runs over the audio rows only, the text is cross-attention memory (valle.py:598-632)
+  const int bos = c.prepend_bos ? 1 : 0, A = bos + P, M = vf ? A : S + A, d = c.d_model;
   if (S > c.max_text || A + 1 > c.max_audio) return fail(VX_ERR_CAPACITY, "S=%d / P=%d exceed capacity", S, P);
   if (A == 0) return fail(VX_ERR_ARG, "empty audio prefix needs prepend_bos");
   if (slot >= e->bmax) return fail(VX_ERR_ARG, "slot %d >= max_batch %d", slot, e->bmax);
@@ -962,25 +1070,30 @@ static int prefill_impl(vx_engine* e, int slot, const int64_t* text, int32_t S, 
     embed_accum_kernel<<<S, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "ar_text_embedding.word_embeddings.weight"), 512, d, e->pn_a, S, 1);
     VXC(text_prenet_rows(e, 0, e->pn_a, e->pn_a, S, d));
     add_pos_kernel<<<S, 256, 0, e->es>>>(e->pn_a, d, W<float>(e, "ar_text_position.alpha"), e->pe_ar, 0, e->X, S);
+    if (vf) { VXC(cast_rows(e, e->X, e->Hn, (size_t)S * d)); VXC(memory_kv(e, e->ar_l, e->xkv_ar, S, d, c.nhead)); }
     embed_accum_kernel<<<A, 256, 0, e->es>>>(e->ids_audio, 1, 0, W<float>(e, "ar_audio_embedding.word_embeddings.weight"), 1025 + bos, d, e->pn_a, A, 1);
     VXC(audio_prenet_rows(e, 0, e->pn_a, e->pn_b, A, d));
-    add_pos_kernel<<<A, 256, 0, e->es>>>(e->pn_b, d, W<float>(e, "ar_audio_position.alpha"), e->pe_ar, 0, e->X + (size_t)S * d, A);
+    add_pos_kernel<<<A, 256, 0, e->es>>>(e->pn_b, d, W<float>(e, "ar_audio_position.alpha"), e->pe_ar, 0, e->X + (size_t)(vf ? 0 : S) * d, A);
   } else {
     embed_pos_kernel<<<S, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "ar_text_embedding.word_embeddings.weight"), 512, d,
                                            W<float>(e, "ar_text_position.alpha"), e->pe_ar, 0, e->X, S);
+    // VALL-F: the text rows become the per-layer memory K / V (projected once, valle.py:598-602), then the audio rows take X
+    if (vf) { VXC(cast_rows(e, e->X, e->Hn, (size_t)S * d)); VXC(memory_kv(e, e->ar_l, e->xkv_ar, S, d, c.nhead)); }
     embed_pos_kernel<<<A, 256, 0, e->es>>>(e->ids_audio, 1, 0, W<float>(e, "ar_audio_embedding.word_embeddings.weight"), 1025 + bos, d,
-                                           W<float>(e, "ar_audio_position.alpha"), e->pe_ar, 0, e->X + (size_t)S * d, A);
+                                           W<float>(e, "ar_audio_position.alpha"), e->pe_ar, 0, e->X + (size_t)(vf ? 0 : S) * d, A);
   }
   char* kv_base = slot < 0 ? (char*)e->kv : (char*)(e->bkv + (size_t)slot * e->bkv_slot);
   float* x_dst = slot < 0 ? e->ar_x : e->bx + (size_t)slot * d;
   float* lg_dst = slot < 0 ? e->ar_logits : e->blogits + (size_t)slot * LOGITS_CUR;
   ArState* st_dst = slot < 0 ? e->d_st : e->bst + slot;
-  VXC(run_stack(e, e->ar_l, M, d, c.nhead, S, -1, true, kv_base));
+  if (vf) { e->mem_len = S; VXC(run_stack_f(e, e->ar_l, M, d, c.nhead, 0, -1, true, e->xkv_ar, S)); }
+  else VXC(run_stack(e, e->ar_l, M, d, c.nhead, S, -1, true, kv_base));
   HIPC(hipMemcpyAsync(x_dst, e->X + (size_t)(M - 1) * d, (size_t)d * 4, hipMemcpyDeviceToDevice, e->es));
   // decode state as of "pass 0 computed"
   ArState& st = slot < 0 ? e->h_st[0] : e->h_bst[slot];
   memset(&st, 0, sizeof st);
   st.S = S; st.bos = bos; st.P = P; st.row = M - 1; st.pass = 0;
+  st.kv_text = e->vallf ? 0 : S;
   st.temperature = 1.0f; st.max_new = -1;
   st.trace_logits = (slot < 0 && (c.flags & VX_FLAG_TRACE_LOGITS)) ? 1 : 0;
   HIPC(hipMemcpyAsync(st_dst, &st, sizeof st, hipMemcpyHostToDevice, e->es));
@@ -1076,7 +1189,7 @@ extern "C" int vx_batch_prefill_all(vx_engine* e, int32_t n, const int64_t* cons
     HIPC(hipMemcpyAsync(e->bx + (size_t)b * d, e->X + (size_t)(start[b] + len[b] - 1) * d, (size_t)d * 4, hipMemcpyDeviceToDevice, e->es));
     ArState& st = e->h_bst[b];
     memset(&st, 0, sizeof st);
-    st.S = S[b]; st.bos = bos; st.P = P[b]; st.row = len[b] - 1; st.pass = 0;
+    st.S = S[b]; st.bos = bos; st.P = P[b]; st.row = len[b] - 1; st.pass = 0; st.kv_text = S[b];
     st.temperature = 1.0f; st.max_new = -1;
   }
   HIPC(hipMemcpyAsync(e->bst, e->h_bst, (size_t)n * sizeof(ArState), hipMemcpyHostToDevice, e->es));
@@ -1105,7 +1218,9 @@ extern "C" int vx_batch_prefill_all(vx_engine* e, int32_t n, const int64_t* cons
 // One decode step: sample from the newest logits, append, run the 12-layer stack on the new
 // token, produce the next logits.  Every kernel reads its position from e->d_st, so the same
 // launch sequence (captured once as a hipGraph) serves every pass.
+static int enqueue_ar_step_f(vx_engine* e, hipStream_t s);
 static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
+  if (e->vallf) return enqueue_ar_step_f(e, s);
   const vx_config& c = e->cfg;
   const int d = c.d_model, H = c.nhead, hd = d / H;
   const bool post = c.flags & VX_FLAG_POST_NORM;
@@ -1216,6 +1331,109 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     VXC(enqueue_head(e, s));
   }
   return VX_OK;
+}
+
+// The VALL-F decode step (valle.py:613-647 with a KV cache; TransformerDecoderLayer, modules/transformer.py:536-560): per
+// layer QKV GEMV, causal attention over the cached AUDIO rows, out-projection, cross-attention query GEMV (rows [0, d) of the
+// packed multihead_attn in_proj), single-query attention over the layer's cached text memory (fixed length), its
+// out-projection, FFN1, FFN2: 8 launches per layer.  Post-norm: every norm runs in the prologue of the kernel that consumes it
+// and leaves the normalised vector in ar_xn as the next residual base (as in the VALL-E step).
+static int enqueue_ar_step_f(vx_engine* e, hipStream_t s) {
+  const vx_config& c = e->cfg;
+  const int d = c.d_model, H = c.nhead, hd = d / H;
+  const bool post = c.flags & VX_FLAG_POST_NORM;
+  SampleArgs sa{};
+  sa.logits = e->ar_logits; sa.V = AR_VOCAB; sa.st = e->d_st;
+  sa.tokens = e->d_tokens; sa.sampled = e->d_sampled; sa.argmaxes = e->d_argmax;
+  sa.emb = W<float>(e, "ar_audio_embedding.word_embeddings.weight");
+  sa.alpha = W<float>(e, "ar_audio_position.alpha");
+  sa.pe = e->pe_ar; sa.x = e->ar_x; sa.d = d; sa.kid = -1;
+  const bool prenet = c.flags & VX_FLAG_PRENET;
+  if (prenet) { sa.alpha = e->d_zero; sa.x = e->ar_e; }
+  sample_embed4_kernel<5, 17><<<1, 256, 0, s>>>(sa);
+  if (prenet) {
+    GemvArgs p0{}, p1{}, p2{};
+    p0.st = p1.st = p2.st = e->d_st;
+    p0.kid = p1.kid = p2.kid = -1;
+    p0.W = W<void>(e, "ar_audio_prenet.0.weight"); p0.bias = W<float>(e, "ar_audio_prenet.0.bias");
+    p0.x = e->ar_e; p0.y = e->ar_h1; p0.N = PRENET_H; p0.K = d; p0.pro = PRO_COPY; p0.epi = EPI_RELU;
+    p1.W = W<void>(e, "ar_audio_prenet.3.weight"); p1.bias = W<float>(e, "ar_audio_prenet.3.bias");
+    p1.x = e->ar_h1; p1.y = e->ar_h2; p1.N = PRENET_H; p1.K = PRENET_H; p1.pro = PRO_COPY; p1.epi = EPI_RELU;
+    p2.W = W<void>(e, "ar_audio_prenet.6.weight"); p2.bias = W<float>(e, "ar_audio_prenet.6.bias");
+    p2.x = e->ar_h2; p2.y = e->ar_x; p2.N = d; p2.K = PRENET_H; p2.pro = PRO_COPY; p2.epi = EPI_POS;
+    p2.pe = e->pe_ar; p2.pos_alpha = W<float>(e, "ar_audio_position.alpha");
+    VXC(launch_gemv(false, p0, e->num_cu, s));
+    VXC(launch_gemv(false, p1, e->num_cu, s));
+    VXC(launch_gemv(false, p2, e->num_cu, s));
+  }
+  const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd * e->esz;
+  const size_t xkv_layer = (size_t)2 * d * c.max_text * e->esz;
+  const float scale = 1.0f / sqrtf((float)hd);
+  auto attend = [&](const char* kc, const char* vc, int ctx_max, int fixed_ctx) -> int {
+#define ADF(HDV)                                                                                                                       \
+  if (hd == HDV) {                                                                                                                     \
+    if (e->bf16) attn_decode_small_kernel<bf16, HDV><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, ctx_max, scale, -1, fixed_ctx); \
+    else attn_decode_small_kernel<float, HDV><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, ctx_max, scale, -1, fixed_ctx);      \
+    return VX_OK;                                                                                                                      \
+  }
+    if (hd == 64) {
+      if (e->bf16) attn_decode_kernel<bf16, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const bf16*)kc, (const bf16*)vc, e->ar_part, e->d_st, ctx_max, scale, -1, fixed_ctx);
+      else attn_decode_kernel<float, 64><<<H * ATT_NSPLIT, 256, 0, s>>>(e->ar_q, (const float*)kc, (const float*)vc, e->ar_part, e->d_st, ctx_max, scale, -1, fixed_ctx);
+      return VX_OK;
+    }
+    ADF(32) ADF(16) ADF(8) ADF(4)
+#undef ADF
+    return fail(VX_ERR_UNSUPPORTED, "decode attention: head_dim %d", hd);
+  };
+  for (int li = 0; li < c.num_layers; ++li) {
+    const LayerW& l = e->ar_l[li];
+    const char* kc = (const char*)e->kv + (size_t)li * kv_layer;
+    const char* vc = kc + kv_layer / 2;
+    const char* xk = (const char*)e->xkv_ar + (size_t)li * xkv_layer;
+    const char* xv = xk + xkv_layer / 2;
+    const float* res = nullptr;  // residual base of the sub-block (null: ar_x itself)
+    // self-attention
+    GemvArgs a{};
+    a.st = e->d_st; a.d = d; a.hd = hd; a.ctx_max = e->ctx_max; a.nhead = H; a.kid = -1;
+    a.W = l.in_w; a.bias = l.in_b; a.x = e->ar_x; a.gamma = l.n1_g; a.beta = l.n1_b;
+    a.N = 3 * d; a.K = d; a.pro = PRO_LN; a.epi = EPI_QKV; a.q = e->ar_q; a.kcache = (void*)kc; a.vcache = (void*)vc;
+    if (post) {
+      if (li == 0) a.pro = PRO_COPY;  // the fresh embedding, no norm in front of the first block
+      else { a.gamma = e->ar_l[li - 1].n3_g; a.beta = e->ar_l[li - 1].n3_b; a.xnorm_out = e->ar_xn; res = e->ar_xn; }
+    }
+    VXC(launch_gemv(e->bf16, a, e->num_cu, s));
+    VXC(attend(kc, vc, e->ctx_max, 0));
+    GemvArgs o{};
+    o.st = e->d_st; o.hd = hd; o.nhead = H; o.kid = -1;
+    o.W = l.out_w; o.bias = l.out_b; o.part = e->ar_part; o.y = e->ar_x; o.N = d; o.K = d; o.pro = PRO_ATTN; o.epi = EPI_RESID; o.res = res;
+    VXC(launch_gemv(e->bf16, o, e->num_cu, s));
+    // cross-attention: q = in_proj[0:d](norm2(x)) (post-norm: norm1 of the raw sum, which is also the next residual base)
+    GemvArgs q{};
+    q.st = e->d_st; q.kid = -1;
+    q.W = l.cin_w; q.bias = l.cin_b; q.x = e->ar_x; q.y = e->ar_q; q.N = d; q.K = d; q.pro = PRO_LN; q.epi = EPI_BIAS;
+    q.gamma = post ? l.n1_g : l.n2_g; q.beta = post ? l.n1_b : l.n2_b;
+    if (post) q.xnorm_out = e->ar_xn;
+    VXC(launch_gemv(e->bf16, q, e->num_cu, s));
+    VXC(attend(xk, xv, c.max_text, e->mem_len));
+    GemvArgs co{};
+    co.st = e->d_st; co.hd = hd; co.nhead = H; co.kid = -1;
+    co.W = l.cout_w; co.bias = l.cout_b; co.part = e->ar_part; co.y = e->ar_x; co.N = d; co.K = d; co.pro = PRO_ATTN; co.epi = EPI_RESID;
+    co.res = post ? e->ar_xn : nullptr;
+    VXC(launch_gemv(e->bf16, co, e->num_cu, s));
+    // feed-forward
+    GemvArgs f{};
+    f.st = e->d_st; f.kid = -1;
+    f.W = l.w1; f.bias = l.b1; f.x = e->ar_x; f.y = e->ar_f; f.N = 4 * d; f.K = d; f.pro = PRO_LN; f.epi = EPI_RELU;
+    f.gamma = post ? l.n2_g : l.n3_g; f.beta = post ? l.n2_b : l.n3_b;
+    if (post) f.xnorm_out = e->ar_xn;
+    VXC(launch_gemv(e->bf16, f, e->num_cu, s));
+    GemvArgs g{};
+    g.st = e->d_st; g.kid = -1;
+    g.W = l.w2; g.bias = l.b2; g.x = e->ar_f; g.y = e->ar_x; g.N = d; g.K = 4 * d; g.pro = PRO_COPY; g.epi = EPI_RESID;
+    if (post) g.res = e->ar_xn;
+    VXC(launch_gemv(e->bf16, g, e->num_cu, s));
+  }
+  return enqueue_head(e, s);
 }
 
 extern "C" int vx_ar_decode(vx_engine* e, const vx_decode_params* p, void* stream) {
@@ -1557,7 +1775,8 @@ static int nar_impl(vx_engine* e, const int64_t* text_nar, int32_t S2, const int
   ON_DEVICE(c.device);
   VXC(sync_in(e, stream));
   HIPC(hipEventRecord(e->ev_t[4], e->es));
-  const int dn = c.nar_d_model, A = P + T, N = S2 + A;
+  const bool vf = e->vallf;  // VALL-F (valle.py:650-708): the stack runs over the audio rows, the NAR text is cross-attention memory
+  const int dn = c.nar_d_model, A = P + T, N = vf ? A : S2 + A, tx = vf ? 0 : S2;  // tx = text rows in front of the audio rows in X
   // y = [prompt codebook 0 | AR tokens] (valle.py:1064-1066)
   if (P) HIPC(hipMemcpyAsync(e->ids_prompts, prompts, (size_t)P * Q * 8, hipMemcpyDefault, e->es));
   HIPC(hipMemcpyAsync(e->ids_samples, ar_tokens, (size_t)T * 8, hipMemcpyDefault, e->es));
@@ -1578,28 +1797,36 @@ static int nar_impl(vx_engine* e, const int64_t* text_nar, int32_t S2, const int
       VXC(text_prenet_rows(e, 1, e->pn_a, e->pn_a, S2, dn));
       add_pos_kernel<<<S2, 256, 0, e->es>>>(e->pn_a, dn, a_txt, e->pe_nar, 0, e->pn_text, S2);
     }
+    if (vf) {  // the text memory's K / V per layer, once for all stages (same memory and weights in every stage, valle.py:664-688)
+      if (prenet) HIPC(hipMemcpyAsync(e->X, e->pn_text, (size_t)S2 * dn * 4, hipMemcpyDeviceToDevice, e->es));
+      else embed_pos_kernel<<<S2, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "nar_text_embedding.word_embeddings.weight"), 512, dn,
+                                                   a_txt, e->pe_nar, 0, e->X, S2);
+      VXC(cast_rows(e, e->X, e->Hn, (size_t)S2 * dn));
+      VXC(memory_kv(e, e->nar_l, e->xkv_nar, S2, dn, c.nar_nhead));
+    }
     for (int i = 0; i < Q - 1; ++i) {
       if (prenet) {
-        HIPC(hipMemcpyAsync(e->X, e->pn_text, (size_t)S2 * dn * 4, hipMemcpyDeviceToDevice, e->es));
+        if (!vf) HIPC(hipMemcpyAsync(e->X, e->pn_text, (size_t)S2 * dn * 4, hipMemcpyDeviceToDevice, e->es));
         if (pos_before_prenet) {  // VALLE.continual, prefix mode 0 (valle.py:1193-1194)
           add_pos_kernel<<<A, 256, 0, e->es>>>(e->yemb, dn, a_aud, e->pe_nar, 0, e->pn_a, A);
-          VXC(audio_prenet_rows(e, 1, e->pn_a, e->X + (size_t)S2 * dn, A, dn));
+          VXC(audio_prenet_rows(e, 1, e->pn_a, e->X + (size_t)tx * dn, A, dn));
         } else {  // valle.py:1092-1093, 1121-1122
           VXC(audio_prenet_rows(e, 1, e->yemb, e->pn_b, A, dn));
-          add_pos_kernel<<<A, 256, 0, e->es>>>(e->pn_b, dn, a_aud, e->pe_nar, 0, e->X + (size_t)S2 * dn, A);
+          add_pos_kernel<<<A, 256, 0, e->es>>>(e->pn_b, dn, a_aud, e->pe_nar, 0, e->X + (size_t)tx * dn, A);
         }
       } else {
-        embed_pos_kernel<<<S2, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "nar_text_embedding.word_embeddings.weight"), 512, dn,
-                                                a_txt, e->pe_nar, 0, e->X, S2);
-        add_pos_kernel<<<A, 256, 0, e->es>>>(e->yemb, dn, a_aud, e->pe_nar, 0, e->X + (size_t)S2 * dn, A);
+        if (!vf) embed_pos_kernel<<<S2, 256, 0, e->es>>>(e->ids_text, 1, 0, W<float>(e, "nar_text_embedding.word_embeddings.weight"), 512, dn,
+                                                         a_txt, e->pe_nar, 0, e->X, S2);
+        add_pos_kernel<<<A, 256, 0, e->es>>>(e->yemb, dn, a_aud, e->pe_nar, 0, e->X + (size_t)tx * dn, A);
       }
-      VXC(run_stack(e, e->nar_l, N, dn, c.nar_nhead, -1, i, false));
+      if (vf) VXC(run_stack_f(e, e->nar_l, N, dn, c.nar_nhead, -1, i, false, e->xkv_nar, S2));
+      else VXC(run_stack(e, e->nar_l, N, dn, c.nar_nhead, -1, i, false));
       // final AdaLN + predict layer on the T generated rows only (valle.py:1128)
       if (c.flags & VX_FLAG_POST_NORM) {  // no final norm (valle.py:242-246): the rows are already norm2'd
-        VXC(cast_rows(e, e->X + (size_t)(S2 + P) * dn, e->Hn, (size_t)T * dn));
+        VXC(cast_rows(e, e->X + (size_t)(tx + P) * dn, e->Hn, (size_t)T * dn));
       } else {
-        const float* fw = ada_vec(e, i, 2 * c.nar_num_layers);
-        VXC(ln_rows(e, e->X + (size_t)(S2 + P) * dn, W<float>(e, "nar_decoder.norm.norm.weight"),
+        const float* fw = ada_vec(e, i, e->npl * c.nar_num_layers);
+        VXC(ln_rows(e, e->X + (size_t)(tx + P) * dn, W<float>(e, "nar_decoder.norm.norm.weight"),
                     W<float>(e, "nar_decoder.norm.norm.bias"), fw, fw + dn, e->Hn, T, dn));
       }
       VXC(gemm_rows(e, e->Hn, W<void>(e, "nar_predict_layers." + std::to_string(i) + ".weight"), nullptr, e->nar_logits,
@@ -1701,6 +1928,7 @@ static int ensure_rows(vx_engine* e, size_t rows, size_t audio_rows, size_t text
 static int nar_batch_impl(vx_engine* e, int32_t n, const int64_t* const* text_nar, const int32_t* S2,
                           const int64_t* const* prompts, const int32_t* P, const int64_t* const* ar_tokens,
                           const int32_t* T, int64_t* const* codes_out, const int64_t* const* forced, void* stream) {
+  if (e && e->vallf) return fail(VX_ERR_UNSUPPORTED, "vx_nar_batch: VALL-F runs on the batch-1 path only");
   if (!e || !text_nar || !S2 || !prompts || !P || !ar_tokens || !T || !codes_out) return fail(VX_ERR_ARG, "null argument");
   if (!e->finalized) return fail(VX_ERR_STATE, "weights not finalized");
   const vx_config& c = e->cfg;
@@ -1766,7 +1994,7 @@ static int nar_batch_impl(vx_engine* e, int32_t n, const int64_t* const* text_na
     rc = run_stack(e, e->nar_l, (int)rows, dn, c.nar_nhead, -1, i, false);
     if (rc != VX_OK) break;
     const bool post = c.flags & VX_FLAG_POST_NORM;
-    const float* fw = post ? nullptr : ada_vec(e, i, 2 * c.nar_num_layers);
+    const float* fw = post ? nullptr : ada_vec(e, i, e->npl * c.nar_num_layers);
     for (int b = 0; b < n && rc == VX_OK; ++b) {  // final AdaLN (pre-norm only) on the generated rows, compacted to [sum T][dn]
       const float* xr = e->X + (size_t)(start[b] + S2[b] + P[b]) * dn;
       bf16* hr = (bf16*)e->Hn + (size_t)toff[b] * dn;
@@ -1983,7 +2211,7 @@ extern "C" int vx_op_sample(const float* logits, int32_t V, int32_t top_k, float
   if (V < 2 || V > 2048) return fail(VX_ERR_UNSUPPORTED, "sample: V=%d", V);
   hipStream_t s = (hipStream_t)stream;
   ArState h{};
-  h.S = 1 << 20; h.top_k = top_k; h.temperature = temperature; h.max_new = -1;
+  h.S = 1 << 20; h.kv_text = h.S; h.top_k = top_k; h.temperature = temperature; h.max_new = -1;
   h.exp_noise = exp_noise; h.noise_rows = 1; h.seed = 1;
   ArState* dst = nullptr;
   int* scratch = nullptr;

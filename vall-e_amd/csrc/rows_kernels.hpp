@@ -344,6 +344,86 @@ __global__ __launch_bounds__(256) void attn_rows_simple_kernel(const T* __restri
   }
 }
 
+// Cross-attention rows (VALL-F: TransformerDecoderLayer._mha_block, modules/transformer.py:583-596): queries are rows of a
+// (M, ldq) buffer (the projected norm2(x)), keys / values are the text memory of this layer in the decode-cache layout
+// (nhead, ctx_max, HD) - projected once per utterance - and every query sees all Sk keys (no mask: valle.py:631, 687 pass only
+// an all-false key padding mask).  Same walk as attn_rows_simple_kernel: 4 threads per query, 64-key LDS tiles, online softmax.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void cross_attn_rows_kernel(const T* __restrict__ q_, int ldq, const T* __restrict__ kc,
+                                                              const T* __restrict__ vc, int ctx_max, T* __restrict__ out,
+                                                              int ldo, int M, int Sk, float scale) {
+  constexpr int LD = HD + 4;
+  __shared__ __attribute__((aligned(16))) float Ks[64][LD];
+  __shared__ __attribute__((aligned(16))) float Vs[64][LD];
+  const int tid = threadIdx.x, qi = tid >> 2, s = tid & 3;
+  const int h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int row = q0 + qi;
+  const bool qvalid = row < M;
+  float q[HD], o[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) {
+    q[c] = qvalid ? to_f32(q_[(size_t)row * ldq + h * HD + c]) : 0.f;
+    o[c] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  constexpr int CPT = HD / 4;
+  const int lr = tid >> 2, lc = (tid & 3) * CPT;
+  const T* kh = kc + (size_t)h * ctx_max * HD;
+  const T* vh = vc + (size_t)h * ctx_max * HD;
+  for (int kt = 0; kt < Sk; kt += 64) {
+    __syncthreads();
+    {
+      const int kr = kt + lr;
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+        Ks[lr][lc + j] = (kr < Sk) ? to_f32(kh[(size_t)kr * HD + lc + j]) : 0.f;
+        Vs[lr][lc + j] = (kr < Sk) ? to_f32(vh[(size_t)kr * HD + lc + j]) : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+      const int kl = kk * 4 + s, kg = kt + kl;
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; c += 4) {
+        const float4 kv = *reinterpret_cast<const float4*>(&Ks[kl][c]);
+        dot = fmaf(q[c], kv.x, dot); dot = fmaf(q[c + 1], kv.y, dot);
+        dot = fmaf(q[c + 2], kv.z, dot); dot = fmaf(q[c + 3], kv.w, dot);
+      }
+      if (qvalid && kg < Sk) {
+        const float sc = dot * scale;
+        const float mn = fmaxf(m, sc);
+        const float corr = expf(m - mn), p = expf(sc - mn);
+        l = l * corr + p;
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) {
+          const float4 vv = *reinterpret_cast<const float4*>(&Vs[kl][c]);
+          o[c] = o[c] * corr + p * vv.x; o[c + 1] = o[c + 1] * corr + p * vv.y;
+          o[c + 2] = o[c + 2] * corr + p * vv.z; o[c + 3] = o[c + 3] * corr + p * vv.w;
+        }
+        m = mn;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 4; off <<= 1) {
+    const float m2 = __shfl_xor(m, off, WAVE), l2 = __shfl_xor(l, off, WAVE);
+    const float mn = fmaxf(m, m2);
+    const float c1 = (m == -INFINITY) ? 0.f : expf(m - mn), c2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+    l = l * c1 + l2 * c2;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) o[c] = o[c] * c1 + __shfl_xor(o[c], off, WAVE) * c2;
+    m = mn;
+  }
+  if (qvalid) {
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int c = 0; c < HD; ++c)
+      if ((c / CPT) == s) out[(size_t)row * ldo + h * HD + c] = from_f32<T>(o[c] * inv);
+  }
+}
+
 // K/V rows of the prefill -> per-head cache layout (nhead, ctx_max, HD)
 template <typename T>
 __global__ __launch_bounds__(256) void kv_scatter_kernel(const T* __restrict__ qkv, T* __restrict__ kc,

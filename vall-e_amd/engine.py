@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvallex.so")
 
 VX_PREC_F32, VX_PREC_BF16, VX_PREC_FP8_NAR = 0, 1, 2
 BMAX = 64  # slots per engine (csrc/batch_kernels.hpp)
-VX_FLAG_TRACE_LOGITS, VX_FLAG_NO_GRAPH, VX_FLAG_SIMPLE_ROWS, VX_FLAG_POST_NORM, VX_FLAG_PRENET = 1, 2, 4, 8, 16
+VX_FLAG_TRACE_LOGITS, VX_FLAG_NO_GRAPH, VX_FLAG_SIMPLE_ROWS, VX_FLAG_POST_NORM, VX_FLAG_PRENET, VX_FLAG_VALLF = 1, 2, 4, 8, 16, 32
 STOP_REASONS = {0: "none", 1: "eos_argmax", 2: "eos_sample", 3: "length", 4: "max_new"}
 
 
@@ -159,7 +159,8 @@ class Engine:
         c.max_text, c.max_audio, c.device = max_text, max_audio, self.device
         c.flags = (VX_FLAG_TRACE_LOGITS if trace_logits else 0) | (VX_FLAG_NO_GRAPH if no_graph else 0) | \
                   (VX_FLAG_SIMPLE_ROWS if simple_rows else 0) | (0 if getattr(cfg, "norm_first", True) else VX_FLAG_POST_NORM) | \
-                  (VX_FLAG_PRENET if getattr(cfg, "add_prenet", False) else 0)
+                  (VX_FLAG_PRENET if getattr(cfg, "add_prenet", False) else 0) | \
+                  (VX_FLAG_VALLF if getattr(cfg, "is_vallf", False) else 0)
         c.max_batch = int(max_batch)
         self.max_text, self.max_audio, self.trace_logits, self.max_batch = max_text, max_audio, trace_logits, int(max_batch)
         self.mfma_rows = c.precision != VX_PREC_F32 and not simple_rows

@@ -26,6 +26,8 @@ class VALLE:
     ``sampling`` ("device": on-GPU counter RNG seeded from torch's global generator;
     "torch_cpu": reproduce the exact Exp(1) stream torch.multinomial would consume on CPU)."""
 
+    MODEL_NAME = "VALL-E"  # what the EOS line prints and get_model dispatches on (models/__init__.py:98-124)
+
     def __init__(self, d_model: int, nhead: int, num_layers: int, norm_first: bool = True, add_prenet: bool = False,
                  prefix_mode: int = 0, share_embedding: bool = True, nar_scale_factor: float = 1.0, **kwargs):
         self.engine_opts = dict(
@@ -35,14 +37,16 @@ class VALLE:
             max_batch=kwargs.pop("max_batch", 0))
         self.sampling = kwargs.pop("sampling", "device")
         self.print_eos = kwargs.pop("print_eos", True)
-        self.cfg = ModelConfig(decoder_dim=d_model, nhead=nhead, num_decoder_layers=num_layers, norm_first=norm_first,
+        self.cfg = ModelConfig(model_name=self.MODEL_NAME, decoder_dim=d_model, nhead=nhead, num_decoder_layers=num_layers, norm_first=norm_first,
                                add_prenet=add_prenet, prefix_mode=prefix_mode, share_embedding=share_embedding,
                                scale_factor=nar_scale_factor, prepend_bos=kwargs.pop("prepend_bos", False),
                                num_quantizers=kwargs.pop("num_quantizers", 8))
         if kwargs:
             raise TypeError(f"unexpected arguments {sorted(kwargs)}")
-        if (not norm_first or add_prenet) and self.engine_opts.get("max_batch", 0) > 1:
-            raise NotImplementedError("norm_first=False / add_prenet=True run on the batch-1 path only (inference_batch needs the defaults)")
+        if (not norm_first or add_prenet or self.cfg.is_vallf) and self.engine_opts.get("max_batch", 0) > 1:
+            raise NotImplementedError("norm_first=False / add_prenet=True / VALL-F run on the batch-1 path only (inference_batch needs the defaults)")
+        if self.cfg.is_vallf and self.engine_opts["precision"] == "fp8nar":
+            raise NotImplementedError("precision 'fp8nar' is built for VALL-E only")
         # head_dim 64 is the tuned geometry; 4/8/16/32 (the reference's own test: decoder_dim 64, nhead 16, valle_test.py:93-95)
         # run on the plain kernels, batch-1 only
         hds = [d_model // nhead if nhead > 0 and d_model % nhead == 0 else 0]
@@ -72,7 +76,7 @@ class VALLE:
         unexpected = [k for k in state_dict if k not in want]
         bad = [k for k in want if k in state_dict and tuple(state_dict[k].shape) != tuple(want[k])]
         if bad or (strict and (missing or unexpected)):
-            raise RuntimeError(f"Error(s) in loading state_dict for VALLE: missing {missing}, unexpected {unexpected}, "
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: missing {missing}, unexpected {unexpected}, "
                                f"size mismatch {bad}")
         for k in want:
             if k in state_dict:
@@ -162,7 +166,7 @@ class VALLE:
             if not bos:
                 raise SyntaxError("well trained model shouldn't reach here.")  # valle.py:1049-1052
         if self.print_eos:
-            print(f"VALL-E EOS [{P} -> {P + bos + tokens.numel()}]")  # valle.py:1054
+            print(f"{self.MODEL_NAME} EOS [{P} -> {P + bos + tokens.numel()}]")  # valle.py:1054 / 646
         if Q == 1 or tokens.numel() == 0:
             codes = torch.zeros((tokens.numel(), Q), dtype=torch.int64)
             codes[:, 0] = tokens
@@ -250,16 +254,35 @@ class VALLE:
         return codes.unsqueeze(0)
 
 
+class VALLF(VALLE):
+    """The cross-attention variant (valle.py:49-719; ``--model-name VALL-F``): ``inference`` has VALLE.inference's signature and
+    result (valle.py:566-710).  The text is embedded once as the memory of a TransformerDecoder whose target is the audio
+    sequence alone; the reference masks memory positions >= x_lens (all-false for the unpadded batch-1 input it accepts).
+    The reference's VALLF has no ``continual`` and no batched entry point; neither has this one."""
+
+    MODEL_NAME = "VALL-F"
+
+    def continual(self, *a, **k):
+        raise AttributeError("'VALLF' object has no attribute 'continual'")  # valle.py:1139 defines it on VALLE only
+
+    def inference_batch(self, *a, **k):
+        raise NotImplementedError("VALL-F runs on the batch-1 path only")
+
+
 def get_model(params) -> VALLE:
-    """models/__init__.py:98-136 for --model-name VALL-E; the other model families are outside the hot path."""
+    """models/__init__.py:98-136 for --model-name VALL-E / VALL-F; the debug mel-Transformer is outside the hot path."""
     cfg = ModelConfig.from_params(params)
-    if cfg.model_name.lower() not in ("vall-e", "valle"):
-        raise NotImplementedError(f"model {cfg.model_name!r}: only VALL-E is built (DESIGN.md)")
+    if cfg.model_name.lower() in ("vall-f", "vallf"):
+        cls = VALLF
+    elif cfg.model_name.lower() in ("vall-e", "valle"):
+        cls = VALLE
+    else:
+        raise NotImplementedError(f"model {cfg.model_name!r}: only VALL-E and VALL-F are built (DESIGN.md)")
     extra = {}
     get = params.get if isinstance(params, dict) else lambda k, d=None: getattr(params, k, d)
     for k in ("precision", "max_text", "max_audio", "sampling"):
         if get(k, None) is not None:
             extra[k] = get(k)
-    return VALLE(cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, norm_first=cfg.norm_first, add_prenet=cfg.add_prenet,
+    return cls(cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, norm_first=cfg.norm_first, add_prenet=cfg.add_prenet,
                  prefix_mode=cfg.prefix_mode, share_embedding=cfg.share_embedding, nar_scale_factor=cfg.scale_factor,
                  prepend_bos=cfg.prepend_bos, num_quantizers=cfg.num_quantizers, **extra)

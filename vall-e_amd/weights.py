@@ -24,7 +24,10 @@ import torch
 from .config import NUM_AUDIO_TOKENS, NUM_TEXT_TOKENS, ModelConfig
 
 
-def _encoder_keys(prefix: str, d: int, layers: int, adaptive: bool, final_norm: bool = True) -> "OrderedDict[str, Tuple[int, ...]]":
+def _encoder_keys(prefix: str, d: int, layers: int, adaptive: bool, final_norm: bool = True,
+                  cross: bool = False) -> "OrderedDict[str, Tuple[int, ...]]":
+    """``cross``: the VALL-F stacks are TransformerDecoderLayers (modules/transformer.py:412-500): a second attention
+    module ``multihead_attn`` over the text memory and a third norm, registered in that order."""
     out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     for i in range(layers):
         p = f"{prefix}.layers.{i}"
@@ -32,11 +35,16 @@ def _encoder_keys(prefix: str, d: int, layers: int, adaptive: bool, final_norm: 
         out[f"{p}.self_attn.in_proj_bias"] = (3 * d,)
         out[f"{p}.self_attn.out_proj.weight"] = (d, d)
         out[f"{p}.self_attn.out_proj.bias"] = (d,)
+        if cross:
+            out[f"{p}.multihead_attn.in_proj_weight"] = (3 * d, d)
+            out[f"{p}.multihead_attn.in_proj_bias"] = (3 * d,)
+            out[f"{p}.multihead_attn.out_proj.weight"] = (d, d)
+            out[f"{p}.multihead_attn.out_proj.bias"] = (d,)
         out[f"{p}.linear1.weight"] = (4 * d, d)
         out[f"{p}.linear1.bias"] = (4 * d,)
         out[f"{p}.linear2.weight"] = (d, 4 * d)
         out[f"{p}.linear2.bias"] = (d,)
-        for n in ("norm1", "norm2"):
+        for n in ("norm1", "norm2", "norm3") if cross else ("norm1", "norm2"):
             if adaptive:
                 out[f"{p}.{n}.project_layer.weight"] = (2 * d, d)
                 out[f"{p}.{n}.project_layer.bias"] = (2 * d,)
@@ -88,7 +96,7 @@ def _prenet_keys(prefix: str, d: int) -> "OrderedDict[str, Tuple[int, ...]]":
 
 
 def expected_keys(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
-    """state_dict keys -> shapes for VALLE (valle.py:85-259).  372 entries at L=12 / 8 quantizers with the defaults;
+    """state_dict keys -> shapes for VALLE, and for VALLF when ``cfg.model_name`` names it (valle.py:85-259).  372 entries at L=12 / 8 quantizers with the defaults;
     post-norm models have no final encoder norms, add_prenet adds the four prenets.  Key ORDER follows the
     reference's module registration order."""
     d, dn = cfg.decoder_dim, cfg.nar_dim
@@ -101,7 +109,8 @@ def expected_keys(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
         k.update(_prenet_keys("ar", d))
     k["ar_text_position.alpha"] = (1,)
     k["ar_audio_position.alpha"] = (1,)
-    k.update(_encoder_keys("ar_decoder", d, cfg.num_decoder_layers, adaptive=False, final_norm=cfg.norm_first))
+    cross = cfg.is_vallf
+    k.update(_encoder_keys("ar_decoder", d, cfg.num_decoder_layers, adaptive=False, final_norm=cfg.norm_first, cross=cross))
     k["ar_predict_layer.weight"] = (NUM_AUDIO_TOKENS + 1, d)
     if q > 1:
         k["nar_audio_embeddings.0.word_embeddings.weight"] = (NUM_AUDIO_TOKENS + 1, dn)
@@ -111,7 +120,7 @@ def expected_keys(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
             k.update(_prenet_keys("nar", dn))
         k["nar_text_position.alpha"] = (1,)
         k["nar_audio_position.alpha"] = (1,)
-        k.update(_encoder_keys("nar_decoder", dn, cfg.nar_layers, adaptive=True, final_norm=cfg.norm_first))
+        k.update(_encoder_keys("nar_decoder", dn, cfg.nar_layers, adaptive=True, final_norm=cfg.norm_first, cross=cross))
         for j in range(q - 1):
             k[f"nar_predict_layers.{j}.weight"] = (NUM_AUDIO_TOKENS, dn)
         for j in range(q - 1):
@@ -166,7 +175,7 @@ def synthetic_tensor(key: str, shape: Tuple[int, ...], seed: int = 0) -> torch.T
         return (torch.rand(shape, generator=g) * 2 - 1) * bound
     if key.endswith("in_proj_bias") or key.endswith("out_proj.bias"):
         return torch.randn(shape, generator=g) * 0.02
-    is_ln = (".norm1." in key or ".norm2." in key or "_decoder.norm." in key) and "project_layer" not in key
+    is_ln = (".norm1." in key or ".norm2." in key or ".norm3." in key or "_decoder.norm." in key) and "project_layer" not in key
     if is_ln:
         if key.endswith("weight"):
             return 1.0 + 0.02 * torch.randn(shape, generator=g)
