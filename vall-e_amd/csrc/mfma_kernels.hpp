@@ -22,7 +22,14 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 // lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...): `row & 7` looks right on paper and measures 2-way
 // (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE); tests/probes/lds_conflicts.py checks a swizzle against the groups.  Global->register->LDS staging with
 // the next tile's global loads issued before the current tile's MFMAs (T14 split).
-template <int EPI, bool OUT_F32>
+// RING = 64 / 32: the same tile and epilogues on the staging scheme of the 256^2 kernel below - operands go global -> LDS with
+// global_load_lds_dwordx4 (no staging registers, no ds_write) into a ring of FOUR stages of RING k (128 KB / 64 KB of LDS), the
+// fragments of stage s+1 are read while stage s is multiplied (two register sets), one counted-vmcnt wait + raw s_barrier per
+// stage.  At M ~ 1k rows a CU holds one workgroup = one wave per SIMD, so nothing but the wave's own instruction stream can overlap
+// the LDS phase with the matrix phase: the register-staged loop spends 0.65 us per 64 of k where the MFMAs alone need 0.21.
+// RING = 32 keeps two workgroups per CU possible: grids of 288 workgroups (FFN1 and the split-K slices at 1025 rows) otherwise run
+// as two rounds on 256 CUs.  Its rows are 64 bytes: chunk position = chunk ^ ((0 - (row >> 2)) & 3) (as in the 256^2 kernel).
+template <int EPI, bool OUT_F32, int RING = 0>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                         const float* __restrict__ bias, void* __restrict__ Cv, int M,
                                                         int N, int K, bf16* __restrict__ vt, int vt_n0, int vt_ld, int ld) {
@@ -54,6 +61,116 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
     for (int j = 0; j < 2; ++j) bias_r[j] = bias[min(n0 + wn * 64 + j * 32 + r, N - 1)];
   }
 
+  if constexpr (RING != 0) {
+    constexpr int RK = RING;              // k per stage
+    constexpr int RB = RK * 2;            // bytes per row of a stage
+    constexpr int CPR = RB / 16;          // 16-byte chunks per row: 8 / 4
+    constexpr int KS = RK / 16;           // MFMA k-steps per stage: 4 / 2
+    constexpr int OPB = BM * RB;          // bytes per operand stage: 16 KB / 8 KB
+    constexpr int NI = OPB / 4096;        // LDS-DMA instructions per operand stage: 4 / 2
+    constexpr int ND = 2 * NI;            // ... per stage
+    auto swz = [](int row) { return RB == 128 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
+    const int nk = K / RK;
+    // slot q = tid + 256 i of an operand stage -> row q / CPR = row0 + (256 / CPR) i, position tid % CPR, which holds source chunk
+    // position ^ swz(row); swz has period 16 / 16 rows resp. and 256 / CPR is a multiple of it: the same chunk for every i
+    const int row0 = tid / CPR;
+    const int csrc = ((tid % CPR) ^ swz(row0)) * 8;  // elements
+    const bf16 *sA[NI], *sW[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      sA[i] = A + (size_t)min(m0 + row0 + (256 / CPR) * i, M - 1) * ld + csrc;
+      sW[i] = W + (size_t)min(n0 + row0 + (256 / CPR) * i, N - 1) * ld + csrc;
+    }
+    const int dbase = (tid - lane) * 16;  // wave-uniform LDS byte offset of lane 0's slot (the DMA adds lane * 16)
+    auto stage = [&](int st) {
+      unsigned char* base = lds + (st & 3) * (2 * OPB);
+      const int k0 = st * RK;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sA[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(base + dbase + 4096 * i), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sW[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(base + OPB + dbase + 4096 * i), 16, 0, 0);
+    };
+    bf16x8_t fa0[KS][2], fb0[KS][2], fa1[KS][2], fb1[KS][2];
+    auto lread = [&](int st, bf16x8_t (&fa)[KS][2], bf16x8_t (&fb)[KS][2]) {
+      const unsigned char* ba = lds + (st & 3) * (2 * OPB);
+      const unsigned char* bw = ba + OPB;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = wm * 64 + i * 32 + r;
+          fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(ba + row * RB + (((ks * 2 + h) ^ swz(row)) << 4));
+          const int col = wn * 64 + i * 32 + r;
+          fb[ks][i] = *reinterpret_cast<const bf16x8_t*>(bw + col * RB + (((ks * 2 + h) ^ swz(col)) << 4));
+        }
+    };
+    auto mm = [&](const bf16x8_t (&fa)[KS][2], const bf16x8_t (&fb)[KS][2]) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+    };
+    // Step on stage st (st + 3 < nk): [issue stage st+3 into the slot stage st-1 left two barriers ago] [read the fragments of
+    // stage st+1] [MFMAs of stage st] [counted vmcnt: stage st+2 landed, only stage st+3 may be in flight] [barrier]
+    auto steady = [&](int st, bf16x8_t (&fa)[KS][2], bf16x8_t (&fb)[KS][2], bf16x8_t (&na)[KS][2], bf16x8_t (&nb)[KS][2]) {
+      stage(st + 3);
+      lread(st + 1, na, nb);
+      mm(fa, fb);
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // VMEM (LDS-DMA)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      }
+#pragma unroll
+      for (int i = 0; i < 4 * KS - ND; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * KS / (4 * KS - ND), 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      if (ND == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    };
+    // the last three stages (and short K): nothing, or less, left to issue
+    auto tail = [&](int st, bf16x8_t (&fa)[KS][2], bf16x8_t (&fb)[KS][2], bf16x8_t (&na)[KS][2], bf16x8_t (&nb)[KS][2]) {
+      const bool more = st + 3 < nk;  // uniform
+      if (more) stage(st + 3);
+      if (st + 1 < nk) lread(st + 1, na, nb);
+      mm(fa, fb);
+      if (more && ND == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      else if (more) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    VX_STAMP(0);
+    const int pre = nk < 3 ? nk : 3;
+    for (int st = 0; st < pre; ++st) stage(st);
+    VX_STAMP(1);
+    // stages 0 and 1 landed everywhere (older loads too)
+    if (pre == 3 && ND == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if (pre == 3) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    lread(0, fa0, fb0);
+    VX_STAMP(2);
+    int st = 0;
+    for (; st + 4 < nk; st += 2) {
+      steady(st, fa0, fb0, fa1, fb1);
+      steady(st + 1, fa1, fb1, fa0, fb0);
+    }
+    VX_STAMP(3);
+    for (; st < nk; st += 2) {
+      tail(st, fa0, fb0, fa1, fb1);
+      if (st + 1 < nk) tail(st + 1, fa1, fb1, fa0, fb0);
+    }
+    VX_STAMP(4);
+    // the bias values were loaded at kernel entry; with the hand-counted waits above hipcc no longer knows that they have landed
+    // and put a vmcnt(0) in front of EVERY guarded store of the fp32 epilogue (64 serialised stores, 7 us): one use here, in the
+    // block that dominates the epilogue, settles it
+    asm volatile("" : "+v"(bias_r[0]), "+v"(bias_r[1]));
+  } else {
   // staging: 1024 16-byte chunks per operand tile, 4 per thread; THREE register sets so that three
   // K tiles of global loads are in flight while one is being multiplied (at M ~ 1k rows there is
   // about one workgroup per CU, so nothing else hides the load latency: one tile ahead ran at
@@ -136,6 +253,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
   if (kt < nk) step(I0{}, I1{}, kt);
   if (kt + 1 < nk) step(I1{}, I2{}, kt + 1);
   VX_STAMP(4);
+  }
 
   // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
   if constexpr (!OUT_F32) {
@@ -176,6 +294,32 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
         for (int k = 0; k < 8; ++k) pk.e[k] = tile[(mc * 8 + k) * LDT + nl];
         *reinterpret_cast<uint4*>(vt + (size_t)(n0 + nl - vt_n0) * vt_ld + m0 + mc * 8) = pk.u;
       }
+    }
+  } else if (m0 + BM <= M && n0 + BN <= N) {
+    // full tile (workgroup-uniform): no per-element guards, so the 64 stores of a lane go out back to back, and the residual
+    // form reads all its old values first instead of one dependent load -> add -> store round trip per element
+    float* cbase = reinterpret_cast<float*>(Cv) + (size_t)(m0 + wm * 64 + 4 * h) * N + n0 + wn * 64 + r;
+    float old[2][2][16];
+    if (EPI == GE_RESID) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) old[i][j][v] = cbase[(size_t)(i * 32 + (v & 3) + 8 * (v >> 2)) * N + j * 32];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float bv = bias_r[j];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          float x = acc[i][j][v] + bv;
+          if (EPI == GE_RELU) x = fmaxf(x, 0.f);
+          if (EPI == GE_RESID) x += old[i][j][v];
+          cbase[(size_t)(i * 32 + (v & 3) + 8 * (v >> 2)) * N + j * 32] = x;
+        }
     }
   } else {
 #pragma unroll
@@ -684,6 +828,21 @@ __global__ __launch_bounds__(512) void mfma256w_kernel(const bf16* __restrict__ 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stages issued past the last tile
 }
 
+// Main loop of the 128^2 kernel for a grid of `wgs` workgroups: the LDS-DMA ring with 64-k stages (128 KB of LDS, one workgroup
+// per CU) when the grid fits one round, the 32-k ring (64 KB, two per CU) otherwise.  VX_GEMM_RING = 0 / 32 / 64 forces the
+// register-staged loop / one ring for A/B runs.
+static inline int gemm_ring128(long long wgs) {
+  static const int forced = [] { const char* v = getenv("VX_GEMM_RING"); return (v && *v >= '0' && *v <= '9') ? atoi(v) : -1; }();
+  if (forced == 0 || forced == 32 || forced == 64) return forced;
+  static const int ncu = [] {
+    int dev = 0, cu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+    return cu > 0 ? cu : 256;
+  }();
+  return wgs <= ncu ? 64 : 32;
+}
+
 static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* bias, void* C, int M, int N, int K,
                                      int epi, bool out_f32, hipStream_t s, bf16* vt = nullptr, int vt_n0 = 0,
                                      int vt_ld = 0) {
@@ -741,9 +900,14 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
     static bool attr_done = false;                                                                                      \
     if (!attr_done) {                                                                                                   \
       (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
+      (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<E, F, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+      (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<E, F, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
       attr_done = true;                                                                                                 \
     }                                                                                                                   \
-    mfma_gemm_kernel<E, F><<<grid, 256, 65536, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, K);                       \
+    const int ring = gemm_ring128((long long)grid.x * grid.y);                                                          \
+    if (ring == 64) mfma_gemm_kernel<E, F, 64><<<grid, 256, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, K);   \
+    else if (ring == 32) mfma_gemm_kernel<E, F, 32><<<grid, 256, 65536, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, K); \
+    else mfma_gemm_kernel<E, F><<<grid, 256, 65536, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, K);                  \
   } while (0)
     if (epi == GE_RESID) MG(GE_RESID, true);
     else if (epi == GE_PLAIN) MG(GE_PLAIN, true);
@@ -794,10 +958,15 @@ static inline int mfma_gemm_partial(const bf16* A, const bf16* W, float* slabs, 
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<GE_PLAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<GE_PLAIN, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<GE_PLAIN, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     attr_done = true;
   }
   dim3 grid(N / 128, (M + 127) / 128, splits);
-  mfma_gemm_kernel<GE_PLAIN, true><<<grid, 256, 65536, s>>>(A, W, nullptr, slabs, M, N, K / splits, nullptr, 0, 0, K);
+  const int ring = gemm_ring128((long long)grid.x * grid.y * grid.z);
+  if (ring == 64) mfma_gemm_kernel<GE_PLAIN, true, 64><<<grid, 256, 131072, s>>>(A, W, nullptr, slabs, M, N, K / splits, nullptr, 0, 0, K);
+  else if (ring == 32) mfma_gemm_kernel<GE_PLAIN, true, 32><<<grid, 256, 65536, s>>>(A, W, nullptr, slabs, M, N, K / splits, nullptr, 0, 0, K);
+  else mfma_gemm_kernel<GE_PLAIN, true><<<grid, 256, 65536, s>>>(A, W, nullptr, slabs, M, N, K / splits, nullptr, 0, 0, K);
   return 0;
 }
 
