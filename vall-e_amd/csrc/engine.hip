@@ -850,7 +850,20 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
   const bool mx = mx_on(e, ada_stage, M, d);
   const bool tg = time_gemms() && ada_stage >= 0;  // NAR stages only
   const size_t sstride = (size_t)M * d;
-  const int sp_d = split_for(d), sp_ff = split_for(4 * d);
+  // VX_SPLIT_D / VX_SPLIT_FF (A/B runs): K slices of the out-projection / FFN2 (1 = no slabs, residual add in the GEMM epilogue)
+  static const int env_sp_d = getenv("VX_SPLIT_D") ? atoi(getenv("VX_SPLIT_D")) : 0;
+  static const int env_sp_ff = getenv("VX_SPLIT_FF") ? atoi(getenv("VX_SPLIT_FF")) : 0;
+  auto pick = [](int env, int K, int dflt) { return (env == 1 || env == 2 || env == 4) && K % (64 * env) == 0 ? env : dflt; };
+  // default: the largest of 4 / 2 / 1 slices that keeps (128^2 tiles) x slices within one round of the chip's CUs - at 1025 rows
+  // 72 tiles x 4 slices were 288 workgroups, i.e. two rounds, and four slabs for the next LayerNorm to fold (A/B on one box:
+  // NAR 7 stages 9.38 ms with 4 / 4 slices, 8.97 ms with 2 / 2; the 272-row prefill is fastest with 4 / 4: 0.91 vs 0.99 ms)
+  auto fit = [&](int K) {
+    const long long tiles = (long long)((M + 127) / 128) * (d / 128);
+    for (int sp = split_for(K); sp > 1; sp >>= 1)
+      if (tiles * sp <= e->num_cu) return sp;
+    return 1;
+  };
+  const int sp_d = pick(env_sp_d, d, fit(d)), sp_ff = pick(env_sp_ff, 4 * d, fit(4 * d));
   Fold pend;  // FFN2 slabs of the previous layer, folded by the next norm (pre-norm) or by the trailing fold pass
   for (size_t li = 0; li < layers.size(); ++li) {
     const LayerW& l = layers[li];
@@ -888,7 +901,7 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
     VXC(attn_rows(e, e->QKV, e->ATT, M, d, H, text_len));
     Fold fo;  // out-projection: x += out_proj(attn), folded into the norm that follows when split
     if (tg && !mx) gemm_mark(e, 0);  // (MXFP8 stages: only the fp8 GEMMs are timed; the out-projection stays bf16)
-    if (splitk) {
+    if (splitk && sp_d > 1) {
       VXC(mfma_gemm_partial((const bf16*)e->ATT, (const bf16*)l.out_w, e->slab, M, d, d, sp_d, e->es));
       fo.part = e->slab; fo.nsplit = sp_d; fo.stride = sstride; fo.bias = l.out_b;
     } else {
@@ -910,7 +923,7 @@ static int run_stack(vx_engine* e, const std::vector<LayerW>& layers, int M, int
     if (tg) gemm_mark(e, 0);
     VXC(gemm_rows(e, e->Hn, l.w1, l.b1, e->FF, M, 4 * d, d, GE_RELU, false));
     Fold ff;
-    if (splitk) {
+    if (splitk && sp_ff > 1) {
       VXC(mfma_gemm_partial((const bf16*)e->FF, (const bf16*)l.w2, e->slab, M, d, 4 * d, sp_ff, e->es));
       ff.part = e->slab; ff.nsplit = sp_ff; ff.stride = sstride; ff.bias = l.b2;
     } else {
