@@ -20,7 +20,10 @@ enum GemvPro { PRO_COPY = 0, PRO_LN = 1, PRO_ATTN = 2 };
 enum GemvEpi { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU = 2, EPI_RESID = 3, EPI_QKV = 4, EPI_LOGITS = 5, EPI_POS = 6 };  // POS: + bias + alpha * pe[audio position] (last prenet layer)
 
 constexpr int LOGITS_CUR = 1088;     // floats reserved for the newest logits row at the buffer head; trace rows follow
-constexpr int ATT_NSPLIT = 8;        // key splits per head in the decode attention
+#ifndef VX_ATT_NSPLIT
+#define VX_ATT_NSPLIT 8  // A/B builds: hipcc -DVX_ATT_NSPLIT=4 (profiles/r02_notes.md)
+#endif
+constexpr int ATT_NSPLIT = VX_ATT_NSPLIT;  // key splits per head in the decode attention
 constexpr int ATT_PSTRIDE = 4 + 64;  // floats per partial: {m, l, -, -, o[64]}
 
 struct GemvArgs {
