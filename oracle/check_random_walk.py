@@ -42,7 +42,37 @@ def walk(seed: int):
     return kw, S, P, top_k, temp, enroll
 
 
+def check_vallf(n: int):
+    """The same walk with --model-name VALL-F (valle.py:566-710): the reference's layers under the torch-1.13.1 decoder loop of
+    oracle/ref_harness.py against oracle inference_f; tests/test_gpu_engine.py::test_vallf_random_option_walk_matches_oracle
+    runs the same configurations on the engine."""
+    for seed in range(n):
+        kw, S, P, top_k, temp, enroll = walk(seed)
+        cfg = ModelConfig(model_name="VALL-F", **kw)
+        sd = synthetic_state_dict(cfg, seed=seed)
+        x, xl, y = synthetic_inputs(S, P, 8, seed=50 + seed)
+        noise = None
+        if top_k != 1:
+            torch.manual_seed(7 + seed)
+            noise = torch.stack([torch.empty(1, 1025).exponential_(1)[0] for _ in range(16 * S + 3)])
+        om = vo.OracleModelF(sd, cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, prefix_mode=cfg.prefix_mode, prepend_bos=cfg.prepend_bos,
+                             num_quantizers=cfg.num_quantizers, nar_scale_factor=cfg.scale_factor, norm_first=cfg.norm_first,
+                             add_prenet=cfg.add_prenet)
+        want = vo.inference_f(om, x, xl, y, enroll, top_k, temp, noise)
+        ref = build_reference_model(cfg, sd)
+        torch.manual_seed(7 + seed)
+        with torch.no_grad():
+            got = ref.inference(x, xl, y, enroll_x_lens=enroll, top_k=top_k, temperature=temp)
+        assert got.shape == want.shape and torch.equal(got, want), (seed, kw, S, P, top_k, temp)
+        print(f"VALL-F seed {seed}: d={cfg.decoder_dim} nhead={cfg.nhead} scale={cfg.scale_factor} mode={kw['prefix_mode']} bos={kw['prepend_bos']} "
+              f"Q={kw['num_quantizers']} post={not kw['norm_first']} prenet={kw['add_prenet']} S={S} P={P} top_k={top_k} T={tuple(got.shape)} ok", flush=True)
+    print("all", n, "random VALL-F configurations: oracle == reference")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--vallf":
+        check_vallf(int(sys.argv[2]) if len(sys.argv) > 2 else 24)
+        sys.exit(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 42
     for seed in range(n):
         kw, S, P, top_k, temp, enroll = walk(seed)

@@ -625,3 +625,38 @@ def test_vallf_has_no_continual_and_no_batch():
         m.continual(g.x, g.x_lens, g.y)
     with pytest.raises(NotImplementedError):
         m.inference_batch([(g.x, g.x_lens, g.y)])
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_vallf_random_option_walk_matches_oracle(seed):
+    """The randomised option walk of test_random_option_walk_matches_oracle with --model-name VALL-F: the fp32 engine must produce
+    the oracle's codes exactly.  oracle/check_random_walk.py --vallf ran the same 36 configurations through the reference's layers
+    (torch-1.13.1 decoder loop, oracle/ref_harness.py) and asserted oracle == reference."""
+    from oracle import valle_oracle as vo
+    from oracle.check_random_walk import walk
+    from valle_amd.config import ModelConfig
+    from valle_amd.models import VALLF
+    from valle_amd.weights import synthetic_inputs, synthetic_state_dict
+    import __graft_entry__ as ge
+
+    ge.build()
+    kw, S, P, top_k, temp, enroll = walk(seed)
+    cfg = ModelConfig(model_name="VALL-F", **kw)
+    sd = synthetic_state_dict(cfg, seed=seed)
+    x, xl, y = synthetic_inputs(S, P, 8, seed=50 + seed)
+    om = vo.OracleModelF(sd, cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, prefix_mode=cfg.prefix_mode, prepend_bos=cfg.prepend_bos,
+                         num_quantizers=cfg.num_quantizers, nar_scale_factor=cfg.scale_factor, norm_first=cfg.norm_first, add_prenet=cfg.add_prenet)
+    noise = None
+    if top_k != 1:
+        torch.manual_seed(7 + seed)
+        noise = torch.stack([torch.empty(1, 1025).exponential_(1)[0] for _ in range(16 * S + 3)])
+    want = vo.inference_f(om, x, xl, y, enroll, top_k, temp, noise)
+    m = VALLF(cfg.decoder_dim, cfg.nhead, cfg.num_decoder_layers, norm_first=cfg.norm_first, add_prenet=cfg.add_prenet, prefix_mode=cfg.prefix_mode,
+              share_embedding=cfg.share_embedding, nar_scale_factor=cfg.scale_factor, prepend_bos=cfg.prepend_bos, num_quantizers=cfg.num_quantizers,
+              precision="fp32", max_text=32, max_audio=400, print_eos=False)
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    got = m.inference(x.cuda(), xl.cuda(), y.cuda(), enroll, top_k=top_k, temperature=temp,
+                      exp_noise=None if noise is None else noise.cuda()).cpu()
+    assert got.shape == want.shape, (kw, S, P, top_k, temp)
+    assert torch.equal(got, want), (kw, S, P, top_k, temp)

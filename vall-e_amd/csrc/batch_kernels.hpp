@@ -34,23 +34,31 @@ struct BgemmArgs {
   int logits_stride;
   float* trace;       // BE_LOGITS, optional (VX_FLAG_TRACE_LOGITS): (slots, trace_rows, N) - row `pass` of every live slot
   int trace_rows;
+  // cache warm-up for a LATER GEMM of the step (as GemvArgs.pf of the batch-1 step): workgroup b touches bytes
+  // [b pf_slice, (b+1) pf_slice) of `pf` with 8 unused 16-byte loads per lane.  Speed only.
+  const void* pf;
+  unsigned pf_slice, pf_total;
 };
 
 // C[b][n] = sum_k A[b][k] W[n][k] on v_mfma_f32_16x16x32_bf16: one workgroup = one 16-row n tile (x one K
 // group), its 4 waves take 4 K slices of NS steps and are summed through LDS in wave order.  Lane
 // (c = l&15, g = l>>4) holds act[b = c (+16)][8g..8g+8) and W[n0 + c][8g..8g+8) of each 32-wide step; the
 // accumulator has n on the lane and b = 4g + v in its 4 registers.
-template <int EPI, int NS, int NH>  // NH 16-row halves of slots: 2 (B <= 32) or 4 (B <= 64)
-__global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
+// The operands of the kernel's FIRST loads (A, W, sizes) are explicit leading arguments: with the build's
+// `-amdgpu-kernarg-preload-count` they arrive in SGPRs at wave launch (hipcc does not preload by-value structs), so the weight
+// and activation loads do not wait for a kernarg fetch.  nk = (N << 16) | K.
+template <int EPI, int NS, int NH, bool PF = false>  // NH 16-row halves of slots: 2 (B <= 32) or 4 (B <= 64)
+__global__ __launch_bounds__(256) void bgemm_kernel(const bf16* __restrict__ A_, const bf16* __restrict__ W_, unsigned nk, int kgroups,
+                                                    const BgemmArgs a) {
   __shared__ float red[4][4 * NH][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int ntile = blockIdx.x / a.kgroups, kg = blockIdx.x - ntile * a.kgroups;
+  const int ntile = blockIdx.x / kgroups, kg = blockIdx.x - ntile * kgroups;
   const int n0 = ntile * 16;
-  const int K = a.K;
-  const int kbeg = kg * (K / a.kgroups) + wave * NS * 32;
-  const bf16* wp = a.W + (size_t)min(n0 + c, a.N - 1) * K + kbeg + 8 * g;
-  const bf16* ap = a.A + (size_t)c * K + kbeg + 8 * g;
+  const int K = (int)(nk & 0xffffu), Nn = (int)(nk >> 16);
+  const int kbeg = kg * (K / kgroups) + wave * NS * 32;
+  const bf16* wp = W_ + (size_t)min(n0 + c, Nn - 1) * K + kbeg + 8 * g;
+  const bf16* ap = A_ + (size_t)c * K + kbeg + 8 * g;
   // epilogue operands first (clamped, unconditional): fetched after the K loop they are one more exposed memory round trip
   float bias_v = 0.f;
   if (EPI == BE_QKV || EPI == BE_RELU) bias_v = a.bias[min(n0 + c, a.N - 1)];
@@ -71,6 +79,14 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
   for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int h = 0; h < NH; ++h) af[h][s] = *reinterpret_cast<const bf16x8b_t*>(ap + (size_t)16 * h * K + s * 32);
+  // a later GEMM's weights, requested behind this kernel's own loads (vmcnt retires in order: the waits of the MFMAs do not cover them)
+  uint4 pfv[PF ? 8 : 1];
+  if (PF) {
+    const unsigned lim = min(a.pf_slice, a.pf_total - min(a.pf_total, blockIdx.x * a.pf_slice));
+    const char* pb = reinterpret_cast<const char*>(a.pf) + min((size_t)blockIdx.x * a.pf_slice, (size_t)a.pf_total - 16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pfv[i] = *reinterpret_cast<const uint4*>(pb + min((unsigned)(i * 4096 + tid * 16), max(lim, 16u) - 16u));
+  }
   f32x4_t acc[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) acc[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -111,6 +127,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
         base[((size_t)h * a.ctx_max + st_row[u]) * a.hd + cc] = (bf16)v;
       }
     }
+  }
+  if (PF) {  // the warm-up loads stay live (and unwaited) until here
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(pfv[i].x), "v"(pfv[i].y), "v"(pfv[i].z), "v"(pfv[i].w));
   }
 }
 

@@ -1578,12 +1578,26 @@ extern "C" int vx_ar_result(vx_engine* e, int64_t* tokens, int32_t capacity, int
 
 // ------------------------------------------------------------------------------ batched AR decode
 template <int EPI, int NH> static int launch_bgemm_h(const BgemmArgs& a, int ns, int grid, hipStream_t s) {
-  if (ns == 1) bgemm_kernel<EPI, 1, NH><<<grid, 256, 0, s>>>(a);
-  else if (ns == 2) bgemm_kernel<EPI, 2, NH><<<grid, 256, 0, s>>>(a);
-  else if (ns == 4) bgemm_kernel<EPI, 4, NH><<<grid, 256, 0, s>>>(a);
-  else if (ns == 8) bgemm_kernel<EPI, 8, NH><<<grid, 256, 0, s>>>(a);
-  else return fail(VX_ERR_UNSUPPORTED, "bgemm: %d steps per wave", ns);
-  return VX_OK;
+  if (a.N > 65535 || a.K > 65535) return fail(VX_ERR_UNSUPPORTED, "bgemm: N=%d K=%d", a.N, a.K);  // (N << 16) | K travels as one argument
+  const unsigned nk = ((unsigned)a.N << 16) | (unsigned)a.K;
+#define BG(NSV)                                                                                              \
+  if (ns == NSV) {                                                                                           \
+    if (a.pf != nullptr) bgemm_kernel<EPI, NSV, NH, true><<<grid, 256, 0, s>>>(a.A, a.W, nk, a.kgroups, a);   \
+    else bgemm_kernel<EPI, NSV, NH><<<grid, 256, 0, s>>>(a.A, a.W, nk, a.kgroups, a);                         \
+    return VX_OK;                                                                                            \
+  }
+  BG(1) BG(2) BG(4) BG(8)
+#undef BG
+  return fail(VX_ERR_UNSUPPORTED, "bgemm: %d steps per wave", ns);
+}
+// Points `a` at the weights of a later GEMM of the batched step (BgemmArgs.pf): an even share per workgroup, 32 KB at most.
+static void bgemm_prefetch(BgemmArgs& a, const void* Wn, int Nn, int Kn) {
+  const size_t total = (size_t)Nn * Kn * 2;
+  const int grid = ((a.N + 15) / 16) * a.kgroups;
+  if (Wn == nullptr || total >= (1ull << 32) || total < 16 || grid <= 0) return;
+  size_t slice = ((total + grid - 1) / grid + 15) & ~(size_t)15;
+  if (slice > 32768) slice = 32768;
+  a.pf = Wn; a.pf_slice = (unsigned)slice; a.pf_total = (unsigned)total;
 }
 template <int EPI> static int launch_bgemm(const BgemmArgs& a, hipStream_t s) {
   const int ns = a.K / (a.kgroups * 128);
@@ -1615,6 +1629,21 @@ static int enqueue_batch_step(vx_engine* e, int B, hipStream_t s) {
   const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd;  // elements
   const float scale = 1.0f / sqrtf((float)hd);
   const int kg_d = kgroups_for(d), kg_ff = kgroups_for(4 * d);
+  // cache warm-up as in the batch-1 step: GEMM i of the step also requests the weights of GEMM i + dist, in step order
+  // [QKV_0, out_0, FFN1_0, FFN2_0, QKV_1, ..., FFN2_{L-1}, head], wrapping into the next step (VX_BATCH_PREFETCH, 0 = off)
+  static const int pf_dist = getenv("VX_BATCH_PREFETCH") ? atoi(getenv("VX_BATCH_PREFETCH")) : 2;
+  struct PfW { const void* W; int N, K; };
+  std::vector<PfW> seq;
+  for (int li = 0; li < L; ++li) {
+    const LayerW& l = e->ar_l[li];
+    seq.push_back({l.in_w, 3 * d, d}); seq.push_back({l.out_w, d, d}); seq.push_back({l.w1, 4 * d, d}); seq.push_back({l.w2, d, 4 * d});
+  }
+  seq.push_back({W<void>(e, "ar_predict_layer.weight"), AR_VOCAB, d});
+  auto warm = [&](BgemmArgs& g, int idx) {
+    if (pf_dist <= 0) return;
+    const PfW& n = seq[(idx + pf_dist) % seq.size()];
+    bgemm_prefetch(g, n.W, n.N, n.K);
+  };
   for (int li = 0; li < L; ++li) {
     const LayerW& l = e->ar_l[li];
     // LN1 (+ the FFN2 partial sums of the previous layer)
@@ -1624,21 +1653,25 @@ static int enqueue_batch_step(vx_engine* e, int B, hipStream_t s) {
     a.st = e->bst; a.B = B; a.d = d; a.hd = hd; a.ctx_max = e->ctx_max;
     a.A = e->bh; a.W = (const bf16*)l.in_w; a.bias = l.in_b; a.N = 3 * d; a.K = d; a.kgroups = 1;
     a.q = e->bq; a.kv = e->bkv + (size_t)li * kv_layer; a.kv_slot_stride = e->bkv_slot; a.kv_v_offset = kv_layer / 2;
+    warm(a, 4 * li);
     VXC(launch_bgemm<BE_QKV>(a, s));
     attn_batch_kernel<64><<<dim3(H, B), 256, 0, s>>>(e->bq, e->bkv + (size_t)li * kv_layer, e->bkv_slot, kv_layer / 2, e->bst,
                                                      e->ctx_max, d, scale, e->batt);
     BgemmArgs o{};
     o.st = e->bst; o.B = B;
     o.A = e->batt; o.W = (const bf16*)l.out_w; o.N = d; o.K = d; o.kgroups = kg_d; o.part = e->bpart;
+    warm(o, 4 * li + 1);
     VXC(launch_bgemm<BE_PARTIAL>(o, s));
     launch_ln_batch(e->bx, e->bpart, kg_d, l.out_b, l.n2_g, l.n2_b, e->bh, B, d, s);
     BgemmArgs f{};
     f.st = e->bst; f.B = B;
     f.A = e->bh; f.W = (const bf16*)l.w1; f.bias = l.b1; f.N = 4 * d; f.K = d; f.kgroups = 1; f.f = e->bff;
+    warm(f, 4 * li + 2);
     VXC(launch_bgemm<BE_RELU>(f, s));
     BgemmArgs g{};
     g.st = e->bst; g.B = B;
     g.A = e->bff; g.W = (const bf16*)l.w2; g.N = d; g.K = 4 * d; g.kgroups = kg_ff; g.part = e->bpart;
+    warm(g, 4 * li + 3);
     VXC(launch_bgemm<BE_PARTIAL>(g, s));
   }
   launch_ln_batch(e->bx, e->bpart, kg_ff, e->ar_l[L - 1].b2, W<float>(e, "ar_decoder.norm.weight"),
@@ -1648,6 +1681,7 @@ static int enqueue_batch_step(vx_engine* e, int B, hipStream_t s) {
   hgm.A = e->bh; hgm.W = W<bf16>(e, "ar_predict_layer.weight"); hgm.N = AR_VOCAB; hgm.K = d; hgm.kgroups = 1;
   hgm.logits = e->blogits; hgm.logits_stride = LOGITS_CUR;
   hgm.trace = e->btrace; hgm.trace_rows = e->btok_stride;
+  warm(hgm, 4 * L);
   VXC(launch_bgemm<BE_LOGITS>(hgm, s));
   return VX_OK;
 }
