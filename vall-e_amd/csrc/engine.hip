@@ -1630,8 +1630,11 @@ static int enqueue_batch_step(vx_engine* e, int B, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)hd);
   const int kg_d = kgroups_for(d), kg_ff = kgroups_for(4 * d);
   // cache warm-up as in the batch-1 step: GEMM i of the step also requests the weights of GEMM i + dist, in step order
-  // [QKV_0, out_0, FFN1_0, FFN2_0, QKV_1, ..., FFN2_{L-1}, head], wrapping into the next step (VX_BATCH_PREFETCH, 0 = off)
-  static const int pf_dist = getenv("VX_BATCH_PREFETCH") ? atoi(getenv("VX_BATCH_PREFETCH")) : 2;
+  // [QKV_0, out_0, FFN1_0, FFN2_0, QKV_1, ..., FFN2_{L-1}, head], wrapping into the next step.  OFF by default
+  // (VX_BATCH_PREFETCH=<dist> turns it on): at 32 slots it measured 528-531 us per step against 524-526 without
+  // (profiles/r02_ab_batch_prefetch.log) - between two GEMMs of the batched step sit an attention kernel that streams 87 MB of
+  // K / V and the LayerNorm, and the memory system is not idle as in the batch-1 step.
+  static const int pf_dist = getenv("VX_BATCH_PREFETCH") ? atoi(getenv("VX_BATCH_PREFETCH")) : 0;
   struct PfW { const void* W; int N, K; };
   std::vector<PfW> seq;
   for (int li = 0; li < L; ++li) {
