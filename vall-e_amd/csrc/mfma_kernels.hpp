@@ -991,7 +991,7 @@ __device__ __forceinline__ float xor32_f(float v) {
 // (flash-decoding inside the workgroup).  Used when the (query block, head) grid alone gives each CU about one
 // workgroup (batch-1 NAR: 272 workgroups of 2 waves left two of the four SIMDs of every CU idle).
 template <int NW, int KG>
-__global__ __launch_bounds__(NW * KG * 64) void mfma_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
+__global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ vt,
                                                                  bf16* __restrict__ out, int M, int vt_ld, int d,
                                                                  int text_len, const int* __restrict__ seg_start,
                                                                  const int* __restrict__ seg_len,
@@ -1041,23 +1041,31 @@ __global__ __launch_bounds__(NW * KG * 64) void mfma_attn_kernel(const bf16* __r
   const int ntiles = (blk_limit + 63) / 64;
   const int niter = (ntiles + KG - 1) / KG;  // iteration `it` stages tiles KG*it .. KG*it + KG-1 (past the end: masked)
 
-  uint4 rk[CPT], rv[CPT];
-  auto gload = [&](int it) {
+  // KG == 2 (batch-1 NAR / prefill: about one workgroup per CU, one wave per SIMD): TWO register sets - the tiles of iteration
+  // it+2 are requested while iteration it is multiplied and stored to LDS at the end of iteration it+1, so a load has two
+  // iterations to land.  With one set an iteration took 1.56 us of which ~0.4 us is arithmetic (tests/probes/attn_stamps.py): the
+  // rest was the wait for loads issued one short iteration earlier.  The launch bound keeps the kernel at two workgroups per CU
+  // (the 272-workgroup grid at 1025 rows must stay one round).  Loads are unconditional on a clamped tile index (a load under a
+  // branch makes hipcc's wait in front of the LDS store a vmcnt(0)).
+  constexpr bool TWO = KG == 2;
+  struct TileRegs { uint4 k[CPT], v[CPT]; };
+  TileRegs R0, R1;
+  auto gload = [&](TileRegs& R, int it) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       const int q = tid + i * NT, g = q >> 9, row = (q >> 3) & 63, c = q & 7;
       const int kt = (it * KG + g) * 64;
-      rk[i] = ld16(qkv + (size_t)min(kt + row, M - 1) * ld3 + d + head * HD + c * 8);          // key row, 8 dims
-      rv[i] = ld16(vt + (size_t)(head * HD + row) * vt_ld + min(kt, (vt_ld - 64) & ~63) + c * 8);  // channel row, 8 keys
+      R.k[i] = ld16(qkv + (size_t)min(kt + row, M - 1) * ld3 + d + head * HD + c * 8);          // key row, 8 dims
+      R.v[i] = ld16(vt + (size_t)(head * HD + row) * vt_ld + min(kt, (vt_ld - 64) & ~63) + c * 8);  // channel row, 8 keys
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](const TileRegs& R, int buf) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       const int q = tid + i * NT, g = q >> 9, row = (q >> 3) & 63, c = q & 7;
       const int off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
-      *reinterpret_cast<uint4*>(ldsp(buf, g, 0) + off) = rk[i];
-      *reinterpret_cast<uint4*>(ldsp(buf, g, 1) + off) = rv[i];
+      *reinterpret_cast<uint4*>(ldsp(buf, g, 0) + off) = R.k[i];
+      *reinterpret_cast<uint4*>(ldsp(buf, g, 1) + off) = R.v[i];
     }
   };
 
@@ -1068,12 +1076,20 @@ __global__ __launch_bounds__(NW * KG * 64) void mfma_attn_kernel(const bf16* __r
     for (int v = 0; v < 16; ++v) accO[t][v] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;  // l_run: this half-wave's share of the row sum
 
-  gload(0);
-  lstore(0);
+  VX_STAMP(8);
+  gload(R0, 0);
+  lstore(R0, 0);
+  if (TWO) gload(R1, min(1, niter - 1));
   __syncthreads();
-  for (int it = 0; it < niter; ++it) {
+  VX_STAMP(9);
+  // iteration `it`: tile set it+2 -> RL (the set tile it left), multiply LDS buffer it & 1, tile set it+1 (in RS) -> the other buffer
+  auto step = [&](int it, TileRegs& RL, const TileRegs& RS) {
     const int cur = it & 1, kt = (it * KG + kg) * 64;
-    if (it + 1 < niter) gload(it + 1);
+#ifdef VX_STAMPS
+    if (it < 12) VX_STAMP(10 + it);
+#endif
+    if (TWO) gload(RL, min(it + 2, niter - 1));
+    else if (it + 1 < niter) gload(RL, it + 1);
     const unsigned char* kb = ldsp(cur, kg, 0);
     const unsigned char* vb = ldsp(cur, kg, 1);
     // S^T for the two 32-key sub-tiles
@@ -1149,9 +1165,18 @@ __global__ __launch_bounds__(NW * KG * 64) void mfma_attn_kernel(const bf16* __r
           accO[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v8, pf[sub][s2], accO[t], 0, 0, 0);
         }
       }
-    if (it + 1 < niter) lstore(cur ^ 1);
+    if (it + 1 < niter) lstore(RS, cur ^ 1);
     __syncthreads();
+  };
+  if (TWO) {
+    for (int it = 0; it < niter; it += 2) {
+      step(it, R0, R1);
+      if (it + 1 < niter) step(it + 1, R1, R0);
+    }
+  } else {
+    for (int it = 0; it < niter; ++it) step(it, R0, R0);
   }
+  VX_STAMP(22);
   float l_tot = l_run + xor32_f(l_run);
   if constexpr (KG > 1) {
     // merge the key groups of every query slice: groups 1.. park (m, l, O^T) in LDS (the operand buffers are free after
@@ -1194,6 +1219,7 @@ __global__ __launch_bounds__(NW * KG * 64) void mfma_attn_kernel(const bf16* __r
         *reinterpret_cast<uint2*>(op + t * 32 + 8 * g4 + 4 * hh) = pk.u;
       }
   }
+  VX_STAMP(23);
 }
 
 // (channel, row) transpose of the V third of a packed qkv buffer (only for the stand-alone op test;
