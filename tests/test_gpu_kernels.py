@@ -74,6 +74,40 @@ def test_gemm_bf16(eng, M, N, K, mfma):
     assert (outr - ref.clamp_min(0)).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(16500, 1024, 1024), (16400, 1280, 128), (20000, 768, 384), (66000, 256, 256)])
+@pytest.mark.parametrize("p8", ["1", "0"])
+def test_gemm_bf16_persistent_256_tiles(M, N, K, p8):
+    """More 256^2 tiles than CUs: every persistent workgroup walks two or more tiles (operand stream running on across the tile
+    boundary, counted waits behind an epilogue's stores, ragged last row tile), for the 8-phase kernel and the 32-k ring
+    (VX_GEMM_P8 is read once per process: a child process per setting)."""
+    import subprocess, sys, os
+    from conftest import ROOT
+
+    code = f"""
+import sys, torch
+sys.path.insert(0, {ROOT!r})
+import __graft_entry__ as ge
+ge.build()
+from valle_amd import engine as E
+g = torch.Generator().manual_seed(5)
+A = torch.randn({M}, {K}, generator=g).to(torch.bfloat16).cuda()
+W = (torch.randn({N}, {K}, generator=g) * {K} ** -0.5).to(torch.bfloat16).cuda()
+b = torch.randn({N}, generator=g).cuda()
+ref = torch.nn.functional.linear(A.double(), W.double(), b.double()).float()
+for relu in (False, True):
+    out = E.op_gemm(A, W, b, relu=relu, mfma=True)
+    r = ref.clamp_min(0) if relu else ref
+    err = float((out - r).abs().max())
+    assert err <= 2e-4 * max(1.0, float(r.abs().max())), (relu, err)
+out2 = E.op_gemm(A, W, b, mfma=True)
+assert torch.equal(out2, E.op_gemm(A, W, b, mfma=True))
+print("ok")
+"""
+    env = dict(os.environ, VX_GEMM_P8=p8)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_mfma_gemm_layout_asymmetric(eng):
     """A = I against an asymmetric W catches a transposed C write (cdna guide §3)."""
     K = 128

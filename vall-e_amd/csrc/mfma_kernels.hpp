@@ -678,6 +678,279 @@ __global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stages issued past the last tile
 }
 
+// ---- the 256x256 GEMM on an 8-phase ping-pong schedule (cdna_hip_programming.md, "The 256^2 8-phase template") ----
+// Same tile, wave grid (2 x 4, 128 x 64 per wave), fragment order and epilogue as mfma256_kernel; what changes is WHEN things happen.
+//  * K is consumed in tiles of 64 (128-byte rows, chunk position = chunk ^ ((row >> 1) & 7)).  A K-tile lives in one of two 64 KB
+//    buffers as FOUR 16 KB half-tiles, cut along the waves' register sub-tiles rather than along the tile: A-h0 / A-h1 hold the
+//    first / second 64 rows of BOTH row groups, B-h0 / B-h1 the first / second 32 columns of all four column groups.
+//  * A K-tile is four PHASES; phase p multiplies one quadrant of the wave's 128 x 64 output (16 MFMAs):
+//        p0: read A-sub0 (8 ds_read_b128) + B-sub0 (4), multiply A0 x B0      p1: read B-sub1 (4), A0 x B1
+//        p2: read A-sub1 (8), A1 x B1                                           p3: no reads, A1 x B0
+//    Each phase = [fragment reads + ONE half-tile staged by LDS-DMA (2 loads per lane) + counted vmcnt] barrier [16 MFMAs at raised
+//    priority] barrier.  The two row groups (the two waves of every SIMD) run ONE BARRIER APART: while one multiplies, the other
+//    reads fragments and issues loads, so the matrix pipe and the LDS pipe of a SIMD are both busy all the time.
+//  * The load side is one continuous stream of half-tile "events" in the order A-h0, B-h0, B-h1, A-h1 of K-tile 0, 1, 2, ... running
+//    on across output tiles; phase P issues event P + 6.  Event e is first read in phase e - 1 (e for A-h0) and its slot was last
+//    read in phase e - 8 (.. - 9), i.e. at least two phases before it is overwritten (the guide's WAR rule for staggered groups).
+//    `s_waitcnt vmcnt(8)` in phase P, after that phase's two loads, leaves events P+3 .. P+6 in flight and retires event P+2: read
+//    one phase AFTER the wait that retires it, behind a barrier both groups have passed.  Four half-tiles in flight = four phases
+//    (about a microsecond) for a load to land.
+//  * Output: full tiles store unguarded, so the number of store instructions per lane is a constant (32) and the first four waits
+//    after an epilogue can count them in (`vmcnt(40)`: stores and loads retire in issue order on gfx9) instead of waiting for the
+//    256 KB tile to be acknowledged; ragged tiles, V^T tiles and residual tiles take the plain count (= wait for the stores).
+//    Bias values are loaded before the K loop (the epilogue would otherwise wait for its bias load and, in order, for every
+//    operand load in flight).
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                                       const float* __restrict__ bias, void* __restrict__ Cv, int M, int N,
+                                                       int K, bf16* __restrict__ vt, int vt_n0, int vt_ld, int ntn,
+                                                       int ntiles) {
+  // [2 buffers][A-h0 | B-h0 | B-h1 | A-h1][16 KB], then 8 x 256 B: each wave's 64 bias values of the current tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the stagger barrier below must sit under a scalar branch
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 15, g = lane >> 4;
+  const int G = gridDim.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  auto tile_of = [&](int v) {
+    const int xcd = v & 7, loc = v >> 3;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  };
+  const int cnt = (ntiles - (int)blockIdx.x + G - 1) / G;
+  const int nk = K >> 6;  // K % 128 == 0: an even number of K-tiles, so a K-tile's buffer is its index & 1 in every output tile
+
+  // ---- load side.  A half-tile is 1024 16-byte slots, two per thread: slot tid + 512 i -> local row (tid >> 3) + 64 i, position
+  // tid & 7 holds source chunk (tid & 7) ^ ((row >> 1) & 7) (the same chunk for both, 64 >> 1 being a multiple of 8).
+  // local row -> tile row: A-h(s): (lr >> 6) * 128 + 64 s + (lr & 63); B-h(s): (lr >> 5) * 64 + 32 s + (lr & 31).
+  // Source offsets are rebuilt from two lane constants and scalars at every load (the matrix pipe is the busy one; eight
+  // offsets held in registers were eight registers too many next to 128 accumulators and 64 fragment registers).
+  const int lrow = tid >> 3;
+  const unsigned csrc = (unsigned)(((tid & 7) ^ ((lrow >> 1) & 7)) * 16);
+  const unsigned ldst = (unsigned)(wave * 1024);  // scalar; lane l lands at +16 l
+  const unsigned tb = (unsigned)((lrow >> 5) * 64 + (lrow & 31));
+  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(A);
+  const unsigned char* Wb = reinterpret_cast<const unsigned char*>(W);
+  const unsigned K2 = (unsigned)K * 2u;
+  int l_ord = 0, l_kt = 0, l_m0 = 0, l_n0 = 0;  // the stream's tile (ordinal, first row, first column) and K-tile: scalars
+  auto set_load_tile = [&](int ord) {
+    const int tile = tile_of((int)blockIdx.x + min(ord, cnt - 1) * G);  // past the end: re-read the last tile (never used)
+    const int mt = tile / ntn;
+    l_m0 = mt * 256;
+    l_n0 = (tile - mt * ntn) * 256;
+  };
+  // kind 0: A-h0, 1: B-h0, 2: B-h1, 3: A-h1 of the stream's current K-tile; kind 0 opens the next K-tile
+  auto stage = [&](auto kindc, auto bufc) {
+    constexpr int kind = decltype(kindc)::value, buf = decltype(bufc)::value;
+    constexpr bool isA = kind == 0 || kind == 3;
+    constexpr int sub = (kind == 0 || kind == 1) ? 0 : 1;
+    if (kind == 0) {
+      if (++l_kt == nk) { l_kt = 0; set_load_tile(++l_ord); }
+    }
+    unsigned char* base = lds + buf * 65536 + kind * 16384 + ldst;
+    const unsigned kb = (unsigned)l_kt * 128u + csrc;
+    unsigned o0, o1;
+    if (isA) {
+      const int row = l_m0 + lrow + 64 * sub;
+      o0 = (unsigned)min(row, M - 1) * K2 + kb;
+      o1 = (unsigned)min(row + 128, M - 1) * K2 + kb;
+    } else {
+      o0 = ((unsigned)(l_n0 + 32 * sub) + tb) * K2 + kb;  // N % 256 == 0: always in range
+      o1 = o0 + 128u * K2;
+    }
+    const unsigned char* src = isA ? Ab : Wb;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)o0),
+                                     (__attribute__((address_space(3))) void*)(base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)o1),
+                                     (__attribute__((address_space(3))) void*)(base + 8192), 16, 0, 0);
+  };
+
+  // ---- read side: lane (r, g) reads row r of a 16-row fragment, chunk 4 kk + g, at position chunk ^ ((row >> 1) & 7); fragment
+  // rows start at multiples of 16, so the XOR term is (r >> 1) for all of them
+  const unsigned pos0 = (unsigned)((g ^ (r >> 1)) << 4);
+  const unsigned aoff = (unsigned)((wr * 64 + r) * 128), boff = (unsigned)((wc * 32 + r) * 128);
+  f32x4v_t acc[8][4];
+  bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+  auto read_a = [&](auto bufc, auto subc) {
+    constexpr int buf = decltype(bufc)::value, sub = decltype(subc)::value;
+    const unsigned char* b = lds + buf * 65536 + (sub == 0 ? 0 : 3) * 16384 + aoff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fa[i][kk] = *reinterpret_cast<const bf16x8_t*>(b + i * 2048 + (pos0 ^ (kk * 64)));
+  };
+  auto read_b = [&](auto bufc, auto subc, bf16x8_t (&fb)[2][2]) {
+    constexpr int buf = decltype(bufc)::value, sub = decltype(subc)::value;
+    const unsigned char* b = lds + buf * 65536 + (sub == 0 ? 1 : 2) * 16384 + boff;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fb[j][kk] = *reinterpret_cast<const bf16x8_t*>(b + j * 2048 + (pos0 ^ (kk * 64)));
+  };
+  auto mm = [&](auto ic, auto jc, const bf16x8_t (&fb)[2][2]) {  // quadrant (i0.., j0..) += A-sub x B-sub over the K-tile's two k-steps
+    constexpr int i0 = decltype(ic)::value, j0 = decltype(jc)::value;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[i0 + i][j0 + j], 0, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
+  // phase x of an 8-phase iteration: K-tile buffer (x >> 2) & 1, quadrant x & 3, stages event kind (x + 2) & 3 into buffer
+  // ((x + 6) >> 2) & 1.  laxc: the counted wait lets 32 store instructions through (the four phases behind a full tile's epilogue).
+  auto phase = [&](auto xc, auto laxc) {
+    constexpr int x = decltype(xc)::value;
+    constexpr bool lax = decltype(laxc)::value;
+    constexpr int p = x & 3;
+    using CB = std::integral_constant<int, (x >> 2) & 1>;
+    using SK = std::integral_constant<int, (x + 2) & 3>;
+    using SB = std::integral_constant<int, ((x + 6) >> 2) & 1>;
+    if (p == 0) {
+      read_b(CB{}, I0{}, fb0);
+      read_a(CB{}, I0{});
+    } else if (p == 1) {
+      read_b(CB{}, I1{}, fb1);
+    } else if (p == 2) {
+      read_a(CB{}, I1{});
+    }
+    stage(SK{}, SB{});
+    if (lax) asm volatile("s_waitcnt vmcnt(41)\n\ts_barrier" ::: "memory");  // 8 operand loads + 32 stores + the bias load
+    else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    if (p == 0) mm(I0{}, I0{}, fb0);
+    else if (p == 1) mm(I0{}, I2{}, fb1);
+    else if (p == 2) mm(I4{}, I2{}, fb1);
+    else mm(I4{}, I0{}, fb0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
+  using P4 = std::integral_constant<int, 4>;
+  using P5 = std::integral_constant<int, 5>;
+  using P6 = std::integral_constant<int, 6>;
+  using P7 = std::integral_constant<int, 7>;
+
+  // prologue: events 0..5 (K-tile 0 whole, A-h0 / B-h0 of K-tile 1); events 0 and 1 landed everywhere behind the barrier
+  set_load_tile(0);
+  l_kt = -1;
+  stage(I0{}, I0{});
+  stage(I1{}, I0{});
+  stage(I2{}, I0{});
+  stage(I3{}, I0{});
+  stage(I0{}, I1{});
+  stage(I1{}, I1{});
+  asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  if (wr == 1) asm volatile("s_barrier" ::: "memory");  // the second row group runs one barrier behind the first from here on
+  __builtin_amdgcn_sched_barrier(0);
+
+  int lax = 0;  // scalar flag: the previous tile left exactly 32 store instructions per lane behind its operand loads
+  unsigned char* blds = lds + 131072 + wave * 256;
+  for (int ord = 0; ord < cnt; ++ord) {
+    const int tile = tile_of((int)blockIdx.x + ord * G);
+    const int mt = tile / ntn, nt = tile - mt * ntn;
+    const int m0 = mt * 256, n0 = nt * 256;
+    // the wave's 64 bias values go to its own LDS line by LDS-DMA: older than every operand load of this tile's K loop, so the
+    // counted waits retire it long before the epilogue reads it (a register load would make hipcc drain everything in flight there)
+    if (EPI != GE_PLAIN)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(bias + n0 + wc * 64) + (unsigned)(lane * 4)),
+                                       (__attribute__((address_space(3))) void*)(blds), 4, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+    if (lax) {
+      phase(P0{}, std::true_type{});
+      phase(P1{}, std::true_type{});
+      phase(P2{}, std::true_type{});
+      phase(P3{}, std::true_type{});
+    } else {
+      phase(P0{}, std::false_type{});
+      phase(P1{}, std::false_type{});
+      phase(P2{}, std::false_type{});
+      phase(P3{}, std::false_type{});
+    }
+    phase(P4{}, std::false_type{});
+    phase(P5{}, std::false_type{});
+    phase(P6{}, std::false_type{});
+    phase(P7{}, std::false_type{});
+    for (int t = 2; t < nk; t += 2) {
+      phase(P0{}, std::false_type{});
+      phase(P1{}, std::false_type{});
+      phase(P2{}, std::false_type{});
+      phase(P3{}, std::false_type{});
+      phase(P4{}, std::false_type{});
+      phase(P5{}, std::false_type{});
+      phase(P6{}, std::false_type{});
+      phase(P7{}, std::false_type{});
+    }
+
+    // epilogue: acc[i][j][v] = C[m = m0 + wr*128 + i*16 + r][n = n0 + wc*64 + j*16 + 4g + v]
+    const bool has_vt = !OUT_F32 && vt != nullptr && n0 + 256 > vt_n0;
+    const bool full = m0 + 256 <= M;
+    auto emit = [&](auto guardc) {
+      constexpr bool guard = decltype(guardc)::value;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nb = n0 + wc * 64 + j * 16 + 4 * g;
+        f32x4v_t bv = f32x4v_t{0.f, 0.f, 0.f, 0.f};
+        if (EPI != GE_PLAIN) bv = *reinterpret_cast<const f32x4v_t*>(blds + (j * 16 + 4 * g) * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int m = m0 + wr * 128 + i * 16 + r;
+          float x[4] = {acc[i][j][0] + bv[0], acc[i][j][1] + bv[1], acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
+          if (EPI == GE_RELU) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) x[v] = fmaxf(x[v], 0.f);
+          }
+          if (!guard || m < M) {
+            if (OUT_F32) {
+              float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (size_t)m * N + nb);
+              if (EPI == GE_RESID) {
+                const float4 o = *cp;
+                *cp = make_float4(o.x + x[0], o.y + x[1], o.z + x[2], o.w + x[3]);
+              } else {
+                *cp = make_float4(x[0], x[1], x[2], x[3]);
+              }
+            } else {
+              union { bf16 e[4]; uint2 u; } pk;
+#pragma unroll
+              for (int v = 0; v < 4; ++v) pk.e[v] = (bf16)x[v];
+              *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(Cv) + (size_t)m * N + nb) = pk.u;
+              if (vt != nullptr && nb >= vt_n0) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) vt[(size_t)(nb + v - vt_n0) * vt_ld + m] = pk.e[v];
+              }
+            }
+          }
+        }
+      }
+    };
+    if (full) {
+      emit(std::false_type{});
+      // exactly 32 store instructions per lane behind the operand loads in flight; V^T and residual tiles wait for their stores
+      lax = __builtin_amdgcn_readfirstlane((has_vt || EPI == GE_RESID) ? 0 : 1);
+    } else {
+      emit(std::true_type{});
+      lax = 0;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the events issued past the last tile
+  if (wr == 0) asm volatile("s_barrier" ::: "memory");  // every wave has passed the same number of barriers
+}
+
 // ---- the 256x256 GEMM with FULL-LINE staging (see mx256w_kernel in mx_kernels.hpp for the reasoning): a stage is 64 k = 128-byte
 // rows (two MFMA k-steps of 32), TWO LDS buffers of 64 KB, one LDS-DMA wave-instruction = 8 rows x one whole 128-byte line; chunk
 // swizzle position = chunk ^ ((row >> 1) & 7).  Per stage and wave: 8 LDS-DMA loads, 24 fragment reads, 64 MFMAs, one barrier.
@@ -870,6 +1143,9 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
       return cu > 0 ? cu : 256;
     }();
     const int grid256 = ntn * ntm < ncu ? ntn * ntm : ncu;  // one persistent workgroup per CU (128 KB of LDS each)
+    // the 8-phase schedule (default) needs whole pairs of 64-k tiles and 32-bit byte offsets into A and W; VX_GEMM_P8=0: the 32-k ring
+    static const bool p8_on = [] { const char* v = getenv("VX_GEMM_P8"); return !(v && atoi(v) == 0); }();
+    const bool p8 = p8_on && K % 128 == 0 && (size_t)M * K * 2 < 0xFFFF0000ull && (size_t)N * K * 2 < 0xFFFF0000ull;
     static const bool ring256 = [] { const char* v = getenv("VX_GEMM_WIDE"); return !(v && atoi(v) != 0); }();  // VX_GEMM_WIDE=1: the full-line kernel (A/B)
 #define M2(E, F)                                                                                                         \
   do {                                                                                                                  \
@@ -877,9 +1153,11 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
     if (!attr_done) {                                                                                                   \
       (void)hipFuncSetAttribute((const void*)mfma256_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);  \
       (void)hipFuncSetAttribute((const void*)mfma256w_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+      (void)hipFuncSetAttribute((const void*)mfma256p_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
       attr_done = true;                                                                                                 \
     }                                                                                                                   \
-    if (ring256) mfma256_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm); \
+    if (p8) mfma256p_kernel<E, F><<<grid256, 512, 131072 + 2048, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);   \
+    else if (ring256) mfma256_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm); \
     else mfma256w_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);    \
   } while (0)
     if (N % 256 == 0) {
