@@ -19,7 +19,24 @@ def dmalloc(nbytes, fill=0x3c):
     return p
 
 
-A, W, bias, Cm = dmalloc(M * K * 2), dmalloc(N * K * 2), dmalloc(N * 4, 0), dmalloc(M * N * 4, 0)
+def drandom_bf16(n, seed):
+    """bf16 values of random sign and mantissa with magnitudes in [2^-4, 2): constant operands let the clock run higher than real
+    data does (cdna guide, methodology rule 25), and MFMA-busy fractions are quoted against elapsed cycles."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    bits = (rng.integers(0, 2, n, dtype=np.uint16) << 15) | (rng.integers(0x3D80, 0x4000, n, dtype=np.uint16))
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), C.c_size_t(n * 2)) == 0
+    assert hip.hipMemcpy(p, bits.ctypes.data_as(C.c_void_p), C.c_size_t(n * 2), 1) == 0
+    return p
+
+
+if os.environ.get("VX_PMC_CONST"):
+    A, W = dmalloc(M * K * 2), dmalloc(N * K * 2)
+else:
+    A, W = drandom_bf16(M * K, 1), drandom_bf16(N * K, 2)
+bias, Cm = dmalloc(N * 4, 0), dmalloc(M * N * 4, 0)
 lib.vx_op_gemm.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]
 for _ in range(iters):
     rc = lib.vx_op_gemm(1, 1, A, W, bias, Cm, M, N, K, 0, None)

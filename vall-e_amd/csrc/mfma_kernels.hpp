@@ -684,14 +684,16 @@ __global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A
 //    buffers as FOUR 16 KB half-tiles, cut along the waves' register sub-tiles rather than along the tile: A-h0 / A-h1 hold the
 //    first / second 64 rows of BOTH row groups, B-h0 / B-h1 the first / second 32 columns of all four column groups.
 //  * A K-tile is four PHASES; phase p multiplies one quadrant of the wave's 128 x 64 output (16 MFMAs):
-//        p0: read A-sub0 (8 ds_read_b128) + B-sub0 (4), multiply A0 x B0      p1: read B-sub1 (4), A0 x B1
-//        p2: read A-sub1 (8), A1 x B1                                           p3: no reads, A1 x B0
+//        p0: read A-sub0 (8 ds_read_b128), multiply A0 x B0       p1: read B-sub1 (4), A0 x B1
+//        p2: read A-sub1 (8), A1 x B0                               p3: read B-sub0 of the NEXT K-tile (4), A1 x B1
+//    (SCHED 0, kept for A/B: B-sub0 read with A-sub0 in p0, quadrants A0B0 A0B1 A1B1 A1B0, reads 12 / 4 / 8 / 0)
 //    Each phase = [fragment reads + ONE half-tile staged by LDS-DMA (2 loads per lane) + counted vmcnt] barrier [16 MFMAs at raised
 //    priority] barrier.  The two row groups (the two waves of every SIMD) run ONE BARRIER APART: while one multiplies, the other
 //    reads fragments and issues loads, so the matrix pipe and the LDS pipe of a SIMD are both busy all the time.
 //  * The load side is one continuous stream of half-tile "events" in the order A-h0, B-h0, B-h1, A-h1 of K-tile 0, 1, 2, ... running
-//    on across output tiles; phase P issues event P + 6.  Event e is first read in phase e - 1 (e for A-h0) and its slot was last
-//    read in phase e - 8 (.. - 9), i.e. at least two phases before it is overwritten (the guide's WAR rule for staggered groups).
+//    on across output tiles (B-h0, A-h0, B-h1, A-h1 = the order of first use); phase P issues event P + 6.  Event e is first read
+//    in phase e - 1 and its slot was last read in phase e - 9, three phases before it is overwritten at e - 6 (the guide's WAR rule
+//    for staggered groups asks for two).
 //    `s_waitcnt vmcnt(8)` in phase P, after that phase's two loads, leaves events P+3 .. P+6 in flight and retires event P+2: read
 //    one phase AFTER the wait that retires it, behind a barrier both groups have passed.  Four half-tiles in flight = four phases
 //    (about a microsecond) for a load to land.
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A
 //    256 KB tile to be acknowledged; ragged tiles, V^T tiles and residual tiles take the plain count (= wait for the stores).
 //    Bias values are loaded before the K loop (the epilogue would otherwise wait for its bias load and, in order, for every
 //    operand load in flight).
-template <int EPI, bool OUT_F32>
+template <int EPI, bool OUT_F32, int SCHED = 1>
 __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                        const float* __restrict__ bias, void* __restrict__ Cv, int M, int N,
                                                        int K, bf16* __restrict__ vt, int vt_n0, int vt_ld, int ntn,
@@ -739,11 +741,13 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
     l_m0 = mt * 256;
     l_n0 = (tile - mt * ntn) * 256;
   };
-  // kind 0: A-h0, 1: B-h0, 2: B-h1, 3: A-h1 of the stream's current K-tile; kind 0 opens the next K-tile
+  // SCHED 0: kind 0: A-h0, 1: B-h0, 2: B-h1, 3: A-h1; SCHED 1: kind 0: B-h0, 1: A-h0, 2: B-h1, 3: A-h1 of the stream's current
+  // K-tile (the order of first use); kind 0 opens the next K-tile
+  constexpr int KA0 = SCHED == 0 ? 0 : 1, KB0 = SCHED == 0 ? 1 : 0, KB1 = 2, KA1 = 3;
   auto stage = [&](auto kindc, auto bufc) {
     constexpr int kind = decltype(kindc)::value, buf = decltype(bufc)::value;
-    constexpr bool isA = kind == 0 || kind == 3;
-    constexpr int sub = (kind == 0 || kind == 1) ? 0 : 1;
+    constexpr bool isA = kind == KA0 || kind == KA1;
+    constexpr int sub = (kind == KA0 || kind == KB0) ? 0 : 1;
     if (kind == 0) {
       if (++l_kt == nk) { l_kt = 0; set_load_tile(++l_ord); }
     }
@@ -773,7 +777,7 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
   bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
   auto read_a = [&](auto bufc, auto subc) {
     constexpr int buf = decltype(bufc)::value, sub = decltype(subc)::value;
-    const unsigned char* b = lds + buf * 65536 + (sub == 0 ? 0 : 3) * 16384 + aoff;
+    const unsigned char* b = lds + buf * 65536 + (sub == 0 ? KA0 : KA1) * 16384 + aoff;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -781,7 +785,7 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
   };
   auto read_b = [&](auto bufc, auto subc, bf16x8_t (&fb)[2][2]) {
     constexpr int buf = decltype(bufc)::value, sub = decltype(subc)::value;
-    const unsigned char* b = lds + buf * 65536 + (sub == 0 ? 1 : 2) * 16384 + boff;
+    const unsigned char* b = lds + buf * 65536 + (sub == 0 ? KB0 : KB1) * 16384 + boff;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -811,13 +815,21 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
     using CB = std::integral_constant<int, (x >> 2) & 1>;
     using SK = std::integral_constant<int, (x + 2) & 3>;
     using SB = std::integral_constant<int, ((x + 6) >> 2) & 1>;
-    if (p == 0) {
-      read_b(CB{}, I0{}, fb0);
-      read_a(CB{}, I0{});
-    } else if (p == 1) {
-      read_b(CB{}, I1{}, fb1);
-    } else if (p == 2) {
-      read_a(CB{}, I1{});
+    using NB = std::integral_constant<int, ((x >> 2) & 1) ^ 1>;
+    if (SCHED == 0) {  // fragment reads per phase 12 / 4 / 8 / 0; quadrants A0B0, A0B1, A1B1, A1B0
+      if (p == 0) {
+        read_b(CB{}, I0{}, fb0);
+        read_a(CB{}, I0{});
+      } else if (p == 1) {
+        read_b(CB{}, I1{}, fb1);
+      } else if (p == 2) {
+        read_a(CB{}, I1{});
+      }
+    } else {  // 8 / 4 / 8 / 4: quadrants A0B0, A0B1, A1B0, A1B1, the last phase reads the NEXT K-tile's B-sub0 (B0 is dead by then)
+      if (p == 0) read_a(CB{}, I0{});
+      else if (p == 1) read_b(CB{}, I1{}, fb1);
+      else if (p == 2) read_a(CB{}, I1{});
+      else read_b(NB{}, I0{}, fb0);
     }
     stage(SK{}, SB{});
     if (lax) asm volatile("s_waitcnt vmcnt(41)\n\ts_barrier" ::: "memory");  // 8 operand loads + 32 stores + the bias load
@@ -827,8 +839,8 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
     __builtin_amdgcn_s_setprio(1);
     if (p == 0) mm(I0{}, I0{}, fb0);
     else if (p == 1) mm(I0{}, I2{}, fb1);
-    else if (p == 2) mm(I4{}, I2{}, fb1);
-    else mm(I4{}, I0{}, fb0);
+    else if (p == 2) { if (SCHED == 0) mm(I4{}, I2{}, fb1); else mm(I4{}, I0{}, fb0); }
+    else { if (SCHED == 0) mm(I4{}, I0{}, fb0); else mm(I4{}, I2{}, fb1); }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
@@ -853,6 +865,7 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
   stage(I0{}, I1{});
   stage(I1{}, I1{});
   asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  if (SCHED == 1) read_b(I0{}, I0{}, fb0);  // event 0: B-sub0 of the first K-tile (every later one is read in the phase before its K-tile)
   if (wr == 1) asm volatile("s_barrier" ::: "memory");  // the second row group runs one barrier behind the first from here on
   __builtin_amdgcn_sched_barrier(0);
 
@@ -864,9 +877,12 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
     const int m0 = mt * 256, n0 = nt * 256;
     // the wave's 64 bias values go to its own LDS line by LDS-DMA: older than every operand load of this tile's K loop, so the
     // counted waits retire it long before the epilogue reads it (a register load would make hipcc drain everything in flight there)
-    if (EPI != GE_PLAIN)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(bias + n0 + wc * 64) + (unsigned)(lane * 4)),
+    if (EPI != GE_PLAIN) {
+      unsigned l4 = (unsigned)lane * 4u;
+      asm volatile("" : "+v"(l4));  // rebuilt per tile: hoisted out of the tile loop the 64-bit address was spilled, and its reload drained vmcnt
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(bias + n0 + wc * 64) + l4),
                                        (__attribute__((address_space(3))) void*)(blds), 4, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -907,6 +923,16 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
         const int nb = n0 + wc * 64 + j * 16 + 4 * g;
         f32x4v_t bv = f32x4v_t{0.f, 0.f, 0.f, 0.f};
         if (EPI != GE_PLAIN) bv = *reinterpret_cast<const f32x4v_t*>(blds + (j * 16 + 4 * g) * 4);
+        // residual form: the eight old values of this column group are requested together (the fragment registers are free
+        // now); one load, wait, add, store per element was 32 dependent round trips per lane
+        float4 old[8];
+        if (OUT_F32 && EPI == GE_RESID) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + r;
+            old[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cv) + (size_t)(guard ? min(m, M - 1) : m) * N + nb);
+          }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int m = m0 + wr * 128 + i * 16 + r;
@@ -919,7 +945,7 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
             if (OUT_F32) {
               float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (size_t)m * N + nb);
               if (EPI == GE_RESID) {
-                const float4 o = *cp;
+                const float4 o = old[i];
                 *cp = make_float4(o.x + x[0], o.y + x[1], o.z + x[2], o.w + x[3]);
               } else {
                 *cp = make_float4(x[0], x[1], x[2], x[3]);
@@ -1145,6 +1171,7 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
     const int grid256 = ntn * ntm < ncu ? ntn * ntm : ncu;  // one persistent workgroup per CU (128 KB of LDS each)
     // the 8-phase schedule (default) needs whole pairs of 64-k tiles and 32-bit byte offsets into A and W; VX_GEMM_P8=0: the 32-k ring
     static const bool p8_on = [] { const char* v = getenv("VX_GEMM_P8"); return !(v && atoi(v) == 0); }();
+    static const bool p8_sched0 = [] { const char* v = getenv("VX_GEMM_P8"); return v && atoi(v) == 2; }();  // A/B: the 12/4/8/0 read schedule (f32 + bias form only)
     const bool p8 = p8_on && K % 128 == 0 && (size_t)M * K * 2 < 0xFFFF0000ull && (size_t)N * K * 2 < 0xFFFF0000ull;
     static const bool ring256 = [] { const char* v = getenv("VX_GEMM_WIDE"); return !(v && atoi(v) != 0); }();  // VX_GEMM_WIDE=1: the full-line kernel (A/B)
 #define M2(E, F)                                                                                                         \
@@ -1154,9 +1181,11 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
       (void)hipFuncSetAttribute((const void*)mfma256_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);  \
       (void)hipFuncSetAttribute((const void*)mfma256w_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
       (void)hipFuncSetAttribute((const void*)mfma256p_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
+      (void)hipFuncSetAttribute((const void*)mfma256p_kernel<GE_BIAS, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
       attr_done = true;                                                                                                 \
     }                                                                                                                   \
-    if (p8) mfma256p_kernel<E, F><<<grid256, 512, 131072 + 2048, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);   \
+    if (p8 && p8_sched0 && E == GE_BIAS && F) mfma256p_kernel<GE_BIAS, true, 0><<<grid256, 512, 131072 + 2048, s>>>((const bf16*)A, (const bf16*)W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm); \
+    else if (p8) mfma256p_kernel<E, F><<<grid256, 512, 131072 + 2048, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);   \
     else if (ring256) mfma256_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm); \
     else mfma256w_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);    \
   } while (0)
