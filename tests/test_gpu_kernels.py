@@ -74,7 +74,8 @@ def test_gemm_bf16(eng, M, N, K, mfma):
     assert (outr - ref.clamp_min(0)).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("M,N,K", [(16500, 1024, 1024), (16400, 1280, 128), (20000, 768, 384), (66000, 256, 256)])
+@pytest.mark.parametrize("M,N,K", [(16500, 1024, 1024), (16400, 1280, 128), (20000, 768, 384), (66000, 256, 256),
+                                   (34700, 1024, 4096), (66000, 1024, 2048)])  # the last two: tail tiles split 8 / 4 ways along K
 @pytest.mark.parametrize("p8", ["1", "0"])
 def test_gemm_bf16_persistent_256_tiles(M, N, K, p8):
     """More 256^2 tiles than CUs: every persistent workgroup walks two or more tiles (operand stream running on across the tile
@@ -103,7 +104,7 @@ out2 = E.op_gemm(A, W, b, mfma=True)
 assert torch.equal(out2, E.op_gemm(A, W, b, mfma=True))
 print("ok")
 """
-    env = dict(os.environ, VX_GEMM_P8=p8)
+    env = dict(os.environ, VX_GEMM_P8=p8, VX_GEMM_TAIL="1")  # the tail split is off by default (position-dependent rounding)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 

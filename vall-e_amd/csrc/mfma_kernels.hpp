@@ -6,6 +6,7 @@
 #pragma once
 #include <cstdlib>
 #include <type_traits>
+#include <unordered_map>
 
 #include "common.hpp"
 #include "rows_kernels.hpp"
@@ -702,11 +703,71 @@ __global__ __launch_bounds__(512) void mfma256_kernel(const bf16* __restrict__ A
 //    256 KB tile to be acknowledged; ragged tiles, V^T tiles and residual tiles take the plain count (= wait for the stores).
 //    Bias values are loaded before the K loop (the epilogue would otherwise wait for its bias load and, in order, for every
 //    operand load in flight).
-template <int EPI, bool OUT_F32, int SCHED = 1>
+// Tail split of the persistent 256^2 GEMM (host side: p8_tail_plan): workspace of partial tiles + the split factor (0: none).
+struct P8Tail {
+  float* ws;
+  int split;
+};
+
+// Second launch of a tail-split GEMM: tile a's S partial tiles ([item a S + s][256][256] fp32 in the workspace) summed in item
+// order (fixed, so the result does not depend on timing) + the GEMM's epilogue.  Grid (tail tiles, 16), 256 threads: a block
+// finishes 16 rows x 256 columns, a thread 4 columns of 4 rows.
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(256) void p8_tail_reduce_kernel(const float* __restrict__ ws, int S, int tile0, int ntn, int ntiles,
+                                                             const float* __restrict__ bias, void* __restrict__ Cv, int M, int N,
+                                                             bf16* __restrict__ vt, int vt_n0, int vt_ld) {
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int v = tile0 + (int)blockIdx.x, xcd = v & 7, loc = v >> 3;  // the GEMM's tile order (mfma256p_kernel::tile_of)
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  const int mt = tile / ntn, nt = tile - mt * ntn;
+  const int c4 = (threadIdx.x & 63) * 4, n = nt * 256 + c4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI != GE_PLAIN) bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = (int)blockIdx.y * 16 + it * 4 + ((int)threadIdx.x >> 6), m = mt * 256 + row;
+    const float* p = ws + ((size_t)blockIdx.x * S * 256 + row) * 256 + c4;
+    float4 t = *reinterpret_cast<const float4*>(p);
+    for (int sp = 1; sp < S; ++sp) {
+      const float4 u = *reinterpret_cast<const float4*>(p + (size_t)sp * 65536);
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    float x[4] = {t.x + bv.x, t.y + bv.y, t.z + bv.z, t.w + bv.w};
+    if (EPI == GE_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+    }
+    if (m < M) {
+      if (OUT_F32) {
+        float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (size_t)m * N + n);
+        if (EPI == GE_RESID) {
+          const float4 o = *cp;
+          *cp = make_float4(o.x + x[0], o.y + x[1], o.z + x[2], o.w + x[3]);
+        } else {
+          *cp = make_float4(x[0], x[1], x[2], x[3]);
+        }
+      } else {
+        union { bf16 e[4]; uint2 u; } pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk.e[e] = (bf16)x[e];
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(Cv) + (size_t)m * N + n) = pk.u;
+        if (vt != nullptr && n >= vt_n0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vt[(size_t)(n + e - vt_n0) * vt_ld + m] = pk.e[e];
+        }
+      }
+    }
+  }
+}
+
+#ifndef VX_P8_SCHED
+#define VX_P8_SCHED 1
+#endif
+template <int EPI, bool OUT_F32, int SCHED = VX_P8_SCHED, bool TAIL = false>
 __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                        const float* __restrict__ bias, void* __restrict__ Cv, int M, int N,
                                                        int K, bf16* __restrict__ vt, int vt_n0, int vt_ld, int ntn,
-                                                       int ntiles) {
+                                                       int ntiles, P8Tail tl) {
   // [2 buffers][A-h0 | B-h0 | B-h1 | A-h1][16 KB], then 8 x 256 B: each wave's 64 bias values of the current tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -719,8 +780,27 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
     const int xcd = v & 7, loc = v >> 3;
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
   };
-  const int cnt = (ntiles - (int)blockIdx.x + G - 1) / G;
   const int nk = K >> 6;  // K % 128 == 0: an even number of K-tiles, so a K-tile's buffer is its index & 1 in every output tile
+  // Work items of this workgroup.  Without a tail split: tiles b, b + G, b + 2G, ... over all of K.  With one (tl.split = S in
+  // {2, 4, 8}; the host sets it when the last round would leave most CUs idle): R = ntiles / G whole tiles each, then the
+  // remaining tiles S ways along K: workgroup b < rem * S multiplies K-tiles [s nk / S, (s + 1) nk / S) of tail tile b / S,
+  // s = b % S, into a partial tile of the workspace; a second launch sums the partial tiles and applies the epilogue.
+  const int S = TAIL ? tl.split : 0;  // TAIL = false: everything below folds to the plain tile walk
+  const int R = S > 1 ? ntiles / G : 0;
+  const bool has_tail = S > 1 && (int)blockIdx.x < (ntiles - R * G) * S;
+  const int cnt = S > 1 ? R + (has_tail ? 1 : 0) : (ntiles - (int)blockIdx.x + G - 1) / G;
+  const int tail_a = S > 1 ? (int)blockIdx.x / S : 0, tail_s = S > 1 ? (int)blockIdx.x - tail_a * S : 0;
+  auto item = [&](int ord, int& tile, int& kt0, int& kte) {
+    if (S > 1 && ord >= R) {
+      tile = tile_of(R * G + tail_a);
+      kt0 = tail_s * (nk / S);
+      kte = kt0 + nk / S;
+    } else {
+      tile = tile_of((int)blockIdx.x + ord * G);
+      kt0 = 0;
+      kte = nk;
+    }
+  };
 
   // ---- load side.  A half-tile is 1024 16-byte slots, two per thread: slot tid + 512 i -> local row (tid >> 3) + 64 i, position
   // tid & 7 holds source chunk (tid & 7) ^ ((row >> 1) & 7) (the same chunk for both, 64 >> 1 being a multiple of 8).
@@ -734,12 +814,14 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
   const unsigned char* Ab = reinterpret_cast<const unsigned char*>(A);
   const unsigned char* Wb = reinterpret_cast<const unsigned char*>(W);
   const unsigned K2 = (unsigned)K * 2u;
-  int l_ord = 0, l_kt = 0, l_m0 = 0, l_n0 = 0;  // the stream's tile (ordinal, first row, first column) and K-tile: scalars
+  int l_ord = 0, l_kt = 0, l_kend = 0, l_m0 = 0, l_n0 = 0;  // the stream's item (ordinal, first row, first column), K-tile, last K-tile + 1: scalars
   auto set_load_tile = [&](int ord) {
-    const int tile = tile_of((int)blockIdx.x + min(ord, cnt - 1) * G);  // past the end: re-read the last tile (never used)
+    int tile, kt0;
+    item(min(ord, cnt - 1), tile, kt0, l_kend);  // past the end: re-read the last item (never used)
     const int mt = tile / ntn;
     l_m0 = mt * 256;
     l_n0 = (tile - mt * ntn) * 256;
+    l_kt = kt0;
   };
   // SCHED 0: kind 0: A-h0, 1: B-h0, 2: B-h1, 3: A-h1; SCHED 1: kind 0: B-h0, 1: A-h0, 2: B-h1, 3: A-h1 of the stream's current
   // K-tile (the order of first use); kind 0 opens the next K-tile
@@ -749,7 +831,7 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
     constexpr bool isA = kind == KA0 || kind == KA1;
     constexpr int sub = (kind == KA0 || kind == KB0) ? 0 : 1;
     if (kind == 0) {
-      if (++l_kt == nk) { l_kt = 0; set_load_tile(++l_ord); }
+      if (++l_kt == l_kend) set_load_tile(++l_ord);
     }
     unsigned char* base = lds + buf * 65536 + kind * 16384 + ldst;
     const unsigned kb = (unsigned)l_kt * 128u + csrc;
@@ -832,8 +914,12 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
       else read_b(NB{}, I0{}, fb0);
     }
     stage(SK{}, SB{});
-    if (lax) asm volatile("s_waitcnt vmcnt(41)\n\ts_barrier" ::: "memory");  // 8 operand loads + 32 stores + the bias load
-    else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    if (lax) {  // 8 operand loads + 32 stores (+ the bias load)
+      if (EPI != GE_PLAIN) asm volatile("s_waitcnt vmcnt(41)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(40)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -857,7 +943,7 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
 
   // prologue: events 0..5 (K-tile 0 whole, A-h0 / B-h0 of K-tile 1); events 0 and 1 landed everywhere behind the barrier
   set_load_tile(0);
-  l_kt = -1;
+  --l_kt;
   stage(I0{}, I0{});
   stage(I1{}, I0{});
   stage(I2{}, I0{});
@@ -872,7 +958,9 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
   int lax = 0;  // scalar flag: the previous tile left exactly 32 store instructions per lane behind its operand loads
   unsigned char* blds = lds + 131072 + wave * 256;
   for (int ord = 0; ord < cnt; ++ord) {
-    const int tile = tile_of((int)blockIdx.x + ord * G);
+    int tile, kt0, kte;
+    item(ord, tile, kt0, kte);
+    const bool is_tail = S > 1 && ord >= R;
     const int mt = tile / ntn, nt = tile - mt * ntn;
     const int m0 = mt * 256, n0 = nt * 256;
     // the wave's 64 bias values go to its own LDS line by LDS-DMA: older than every operand load of this tile's K loop, so the
@@ -902,7 +990,7 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
     phase(P5{}, std::false_type{});
     phase(P6{}, std::false_type{});
     phase(P7{}, std::false_type{});
-    for (int t = 2; t < nk; t += 2) {
+    for (int t = kt0 + 2; t < kte; t += 2) {
       phase(P0{}, std::false_type{});
       phase(P1{}, std::false_type{});
       phase(P2{}, std::false_type{});
@@ -916,22 +1004,31 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
     // epilogue: acc[i][j][v] = C[m = m0 + wr*128 + i*16 + r][n = n0 + wc*64 + j*16 + 4g + v]
     const bool has_vt = !OUT_F32 && vt != nullptr && n0 + 256 > vt_n0;
     const bool full = m0 + 256 <= M;
+    unsigned gq = (unsigned)(g * 16);  // lane part of the bias reads, rebuilt per tile (hoisted, one read address per j was spilled: its reload drained vmcnt)
+    asm volatile("" : "+v"(gq));
     auto emit = [&](auto guardc) {
       constexpr bool guard = decltype(guardc)::value;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int nb = n0 + wc * 64 + j * 16 + 4 * g;
         f32x4v_t bv = f32x4v_t{0.f, 0.f, 0.f, 0.f};
-        if (EPI != GE_PLAIN) bv = *reinterpret_cast<const f32x4v_t*>(blds + (j * 16 + 4 * g) * 4);
+        if (EPI != GE_PLAIN) bv = *reinterpret_cast<const f32x4v_t*>(blds + gq + j * 64);
         // residual form: the eight old values of this column group are requested together (the fragment registers are free
-        // now); one load, wait, add, store per element was 32 dependent round trips per lane
-        float4 old[8];
+        // now) by asm loads behind ONE wait that hands the values on: written as plain loads hipcc sinks each one next to its add,
+        // 32 dependent round trips per lane and tile
+        f32x4v_t old[8];
         if (OUT_F32 && EPI == GE_RESID) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int m = m0 + wr * 128 + i * 16 + r;
-            old[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cv) + (size_t)(guard ? min(m, M - 1) : m) * N + nb);
+            const float* op = reinterpret_cast<const float*>(Cv) + (size_t)(guard ? min(m, M - 1) : m) * N + nb;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(old[i]) : "v"(op) : "memory");
           }
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7])
+                       :
+                       : "memory");
+          __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -945,8 +1042,8 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
             if (OUT_F32) {
               float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (size_t)m * N + nb);
               if (EPI == GE_RESID) {
-                const float4 o = old[i];
-                *cp = make_float4(o.x + x[0], o.y + x[1], o.z + x[2], o.w + x[3]);
+                const f32x4v_t o = old[i];
+                *cp = make_float4(o[0] + x[0], o[1] + x[1], o[2] + x[2], o[3] + x[3]);
               } else {
                 *cp = make_float4(x[0], x[1], x[2], x[3]);
               }
@@ -964,7 +1061,19 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
         }
       }
     };
-    if (full) {
+    if (is_tail) {
+      // tail item: the partial tile goes to the workspace as it is ([item][256][256] fp32, same 16-byte pieces as the fp32
+      // epilogue); p8_tail_reduce_kernel, launched behind this kernel, adds the S partial tiles of a tile in a fixed order and
+      // applies the epilogue
+      unsigned lo = (unsigned)((r * 256 + 4 * g) * 4);  // lane part of the address, rebuilt here: hoisted, the 32 store addresses were spilled
+      asm volatile("" : "+v"(lo));
+      unsigned char* slab = reinterpret_cast<unsigned char*>(tl.ws + (size_t)(tail_a * S + tail_s) * 65536 + wr * 32768 + wc * 64) + lo;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4v_t*>(slab + i * 16384 + j * 64) = acc[i][j];
+      lax = 0;
+    } else if (full) {
       emit(std::false_type{});
       // exactly 32 store instructions per lane behind the operand loads in flight; V^T and residual tiles wait for their stores
       lax = __builtin_amdgcn_readfirstlane((has_vt || EPI == GE_RESID) ? 0 : 1);
@@ -1142,6 +1251,40 @@ static inline int gemm_ring128(long long wgs) {
   return wgs <= ncu ? 64 : 32;
 }
 
+// Tail split of the persistent 8-phase GEMM (VX_GEMM_TAIL=1; OFF by default, see below): when the last round of 256^2 tiles would
+// occupy few of the workgroups (544 tiles on 256 CUs: two full rounds, then 32 tiles at the price of a third), those tiles are split
+// S ways along K, every workgroup gets one more, short item that leaves a partial tile in a workspace, and a second, small launch
+// sums the partial tiles in a fixed order and applies the epilogue.  S = the largest of 8 / 4 / 2 with items <= workgroups and >= 8
+// K-tiles per item, and only if the estimate (K loop / S + partial-tile traffic + one launch) is well under the full round it
+// replaces: true at K = 4096, not at K = 1024.  One workspace per stream (<= 64 MB), allocated at first use.
+// Measured (profiles/r02_notes.md): 34816 x 1024 x 4096 322-332 -> 303-308 us, 134144 x 1024 x 4096 943-950 -> 922-925 us: the 128 MB
+// of partial tiles written and read back eat most of the idle round.  Why it is off: a split tile's fp32 sum is S chunk sums added
+// afterwards, a whole tile's is one running sum - deterministic, but a row's rounding then depends on WHICH tile it falls in, and
+// the batched NAR pass loses the property that equal utterances give equal codes whatever their slot (tests/test_gpu_batch.py).
+static inline P8Tail p8_tail_plan(int ntiles, int grid, int K, hipStream_t s) {
+  static const bool on = [] { const char* v = getenv("VX_GEMM_TAIL"); return v && atoi(v) != 0; }();
+  P8Tail tl{nullptr, 0};
+  if (!on || ntiles <= grid || grid > 256) return tl;
+  const int rem = ntiles % grid, nk = K / 64;
+  if (rem == 0 || rem * 2 > grid) return tl;
+  int S = 0;
+  for (int c = 8; c >= 2; c >>= 1)
+    if (rem * c <= grid && nk % (2 * c) == 0 && nk / c >= 8) { S = c; break; }
+  if (S == 0) return tl;
+  // microseconds: 1.5 per K-tile of a 256^2 tile; a partial tile written and read back at ~4 TB/s chip-wide; ~7 for the store
+  // phase and the second launch
+  const float full = 1.5f * nk, split = 1.5f * nk / S + (float)rem * S * 0.262144f * 2.f / 4.f + 7.f;
+  if (split > 0.7f * full) return tl;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return tl;  // no allocation inside a capture
+  static std::unordered_map<hipStream_t, float*> wss;
+  float*& w = wss[s];
+  if (w == nullptr && hipMalloc((void**)&w, (size_t)256 * 262144) != hipSuccess) { w = nullptr; return tl; }
+  tl.ws = w;
+  tl.split = S;
+  return tl;
+}
+
 static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* bias, void* C, int M, int N, int K,
                                      int epi, bool out_f32, hipStream_t s, bf16* vt = nullptr, int vt_n0 = 0,
                                      int vt_ld = 0) {
@@ -1173,6 +1316,7 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
     static const bool p8_on = [] { const char* v = getenv("VX_GEMM_P8"); return !(v && atoi(v) == 0); }();
     static const bool p8_sched0 = [] { const char* v = getenv("VX_GEMM_P8"); return v && atoi(v) == 2; }();  // A/B: the 12/4/8/0 read schedule (f32 + bias form only)
     const bool p8 = p8_on && K % 128 == 0 && (size_t)M * K * 2 < 0xFFFF0000ull && (size_t)N * K * 2 < 0xFFFF0000ull;
+    const P8Tail tl = (p8 && !p8_sched0) ? p8_tail_plan(ntn * ntm, grid256, K, s) : P8Tail{nullptr, 0};  // all forms; in this model only the K = 4096 one (FFN2) ever splits
     static const bool ring256 = [] { const char* v = getenv("VX_GEMM_WIDE"); return !(v && atoi(v) != 0); }();  // VX_GEMM_WIDE=1: the full-line kernel (A/B)
 #define M2(E, F)                                                                                                         \
   do {                                                                                                                  \
@@ -1182,12 +1326,22 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
       (void)hipFuncSetAttribute((const void*)mfma256w_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
       (void)hipFuncSetAttribute((const void*)mfma256p_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
       (void)hipFuncSetAttribute((const void*)mfma256p_kernel<GE_BIAS, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
+      (void)hipFuncSetAttribute((const void*)mfma256p_kernel<E, F, VX_P8_SCHED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
       attr_done = true;                                                                                                 \
     }                                                                                                                   \
-    if (p8 && p8_sched0 && E == GE_BIAS && F) mfma256p_kernel<GE_BIAS, true, 0><<<grid256, 512, 131072 + 2048, s>>>((const bf16*)A, (const bf16*)W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm); \
-    else if (p8) mfma256p_kernel<E, F><<<grid256, 512, 131072 + 2048, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);   \
-    else if (ring256) mfma256_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm); \
-    else mfma256w_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);    \
+    if (p8 && p8_sched0 && E == GE_BIAS && F) {                                                                          \
+      mfma256p_kernel<GE_BIAS, true, 0><<<grid256, 512, 131072 + 2048, s>>>((const bf16*)A, (const bf16*)W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm, tl); \
+    } else if (p8 && tl.split > 1) {                                                                                     \
+      const int nt_all = ntn * ntm, rem_t = nt_all % grid256;                                                           \
+      mfma256p_kernel<E, F, VX_P8_SCHED, true><<<grid256, 512, 131072 + 2048, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, nt_all, tl); \
+      p8_tail_reduce_kernel<E, F><<<dim3(rem_t, 16), 256, 0, s>>>(tl.ws, tl.split, nt_all - rem_t, ntn, nt_all, bias, C, M, N, vt, vt_n0, vt_ld); \
+    } else if (p8) {                                                                                                     \
+      mfma256p_kernel<E, F><<<grid256, 512, 131072 + 2048, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm, tl); \
+    } else if (ring256) {                                                                                                \
+      mfma256_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);        \
+    } else {                                                                                                             \
+      mfma256w_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);       \
+    }                                                                                                                   \
   } while (0)
     if (N % 256 == 0) {
       if (epi == GE_RESID) M2(GE_RESID, true);
