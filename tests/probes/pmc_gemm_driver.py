@@ -1,5 +1,7 @@
 """Torch-free driver: one bf16 GEMM through vx_op_gemm for rocprofv3 --pmc (traffic / MFMA counters).
-usage: python3 tests/probes/pmc_gemm_driver.py M N K [iters]   (VX_GEMM_ALG selects the kernel)"""
+usage: python3 tests/probes/pmc_gemm_driver.py M N K [iters] [form]   (VX_GEMM_ALG selects the kernel)
+form (optional): "bf16" = bf16 output + bias, "qkv" = the same + V^T copy of the last third, "relu" = bf16 output + ReLU, "resid" = fp32
+residual update (vx_op_gemm_rows: the forms the engine's row path launches); default: fp32 output + bias (vx_op_gemm)."""
 import ctypes as C
 import os
 import sys
@@ -10,6 +12,7 @@ lib = C.CDLL(os.path.join(ROOT, "vall-e_amd", "csrc", "libvallex.so"))
 lib.vx_last_error.restype = C.c_char_p
 M, N, K = (int(v) for v in sys.argv[1:4])
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+form = sys.argv[5] if len(sys.argv) > 5 else "f32"
 
 
 def dmalloc(nbytes, fill=0x3c):
@@ -38,8 +41,16 @@ else:
     A, W = drandom_bf16(M * K, 1), drandom_bf16(N * K, 2)
 bias, Cm = dmalloc(N * 4, 0), dmalloc(M * N * 4, 0)
 lib.vx_op_gemm.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]
+lib.vx_op_gemm_rows.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+ld = (M + 255) // 256 * 256
+vt = dmalloc((N // 3) * ld * 2, 0) if form == "qkv" else None
 for _ in range(iters):
-    rc = lib.vx_op_gemm(1, 1, A, W, bias, Cm, M, N, K, 0, None)
+    if form == "f32":
+        rc = lib.vx_op_gemm(1, 1, A, W, bias, Cm, M, N, K, 0, None)
+    elif form == "resid":
+        rc = lib.vx_op_gemm_rows(1, A, W, bias, Cm, M, N, K, 0, None, 0, 0, None)
+    else:
+        rc = lib.vx_op_gemm_rows(0, A, W, bias, Cm, M, N, K, 1 if form == "relu" else 0, vt, N - N // 3 if vt else 0, ld if vt else 0, None)
     assert rc == 0, lib.vx_last_error()
 assert hip.hipDeviceSynchronize() == 0
-print("ok", M, N, K)
+print("ok", M, N, K, form)

@@ -109,6 +109,27 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("M,N,K", [(1025, 3072, 1024), (4100, 768, 256), (8704, 3072, 1024), (34816, 1024, 1024), (20000, 1024, 4096)])
+def test_gemm_rows_forms(eng, M, N, K):
+    """The epilogues the row path itself launches, at M below and above the 256^2 kernel's threshold: bf16 output (+ ReLU) with the
+    V^T copy of the last third of the columns (QKV), and the fp32 residual update (out-projection / FFN2) - the latter applied
+    exactly once (a tile written twice would add its product twice)."""
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    ref = F.linear(A.double(), W.double(), b.double())
+    scale = max(1.0, float(ref.abs().max()))
+    C, vt = eng.op_gemm_rows(A, W, b, vt_cols=N // 3)
+    assert (C.double() - ref).abs().max() <= 2 ** -8 * scale  # one bf16 rounding of an fp32 sum
+    assert torch.equal(vt[:, :M], C[:, N - N // 3:].t())  # the transposed copy holds the same bf16 values
+    Cr, _ = eng.op_gemm_rows(A, W, b, relu=True)
+    assert (Cr.double() - ref.clamp_min(0)).abs().max() <= 2 ** -8 * scale
+    X0 = torch.randn(M, N, generator=g).cuda()
+    X = eng.op_gemm_rows(A, W, b, resid=X0.clone())
+    assert (X.double() - (X0.double() + ref)).abs().max() <= 3e-4 * scale
+
+
 def test_mfma_gemm_layout_asymmetric(eng):
     """A = I against an asymmetric W catches a transposed C write (cdna guide §3)."""
     K = 128

@@ -2182,6 +2182,21 @@ extern "C" int vx_op_gemm(int32_t prec, int32_t mfma, const void* A, const void*
   return VX_OK;
 }
 
+// The row path's own GEMM forms on caller data (bf16 output + V^T copy, fp32 residual update): what run_stack launches for QKV /
+// FFN1 and for the out-projection / FFN2 at M >= 4096.
+extern "C" int vx_op_gemm_rows(int32_t form, const void* A, const void* Wp, const float* bias, void* C, int32_t M, int32_t N,
+                               int32_t K, int32_t relu, void* vt, int32_t vt_n0, int32_t vt_ld, void* stream) {
+  if (!A || !Wp || !C || !bias || M < 1 || N < 1 || K < 1) return fail(VX_ERR_ARG, "gemm_rows: null operand or empty shape");
+  if (form != 0 && form != 1) return fail(VX_ERR_ARG, "gemm_rows: form %d", form);
+  if (vt && (form != 0 || vt_n0 < 0 || vt_n0 >= N || vt_ld < M)) return fail(VX_ERR_ARG, "gemm_rows: V^T copy needs form 0, 0 <= vt_n0 < N, vt_ld >= M");
+  hipStream_t s = (hipStream_t)stream;
+  if (mfma_gemm_dispatch((const bf16*)A, (const bf16*)Wp, bias, C, M, N, K, form == 1 ? GE_RESID : (relu ? GE_RELU : GE_BIAS), form == 1, s,
+                         (bf16*)vt, vt_n0, vt_ld))
+    return fail(VX_ERR_UNSUPPORTED, "gemm_rows: no kernel instance");
+  HIPC(hipGetLastError());
+  return VX_OK;
+}
+
 // MXFP8 GEMM of the NAR stages (mx_kernels.hpp) on caller-supplied fp32 operands: A (M, K) and W (N, K) are quantised on the
 // device exactly as the engine quantises activations / weights, then multiplied by mx256_kernel.  out_mode 0: C (M, N) fp32
 // [bias / ReLU]; 2: the FFN1 form - C as e4m3 bytes (M, N) in c_out and its E8M0 block scales (N/32, ld) in sc_out, ld = M

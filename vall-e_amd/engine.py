@@ -69,6 +69,7 @@ _SIGS = {
     "vx_op_layernorm": (C.c_int, [C.c_int32] + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p]),
     "vx_op_gemv": (C.c_int, [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "vx_op_gemm": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
+    "vx_op_gemm_rows": (C.c_int, [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "vx_op_gemm_mx": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p] * 3),
     "vx_op_layernorm_mx": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_void_p]),
     "vx_op_attention": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]),
@@ -362,6 +363,23 @@ def op_gemm(A, W, bias=None, relu=False, mfma=False):
     _check(lib.vx_op_gemm(_prec(A), int(mfma), _ptr(A), _ptr(W), _ptr(bias), _ptr(Cm), M, N, K, int(relu),
                           current_stream_ptr(A.device)))
     return Cm
+
+
+def op_gemm_rows(A, W, bias, relu=False, resid=None, vt_cols=0):
+    """The engine's row-path GEMM forms (vx_op_gemm_rows) on bf16 A (M, K), W (N, K): resid=None -> (C bf16 (M, N), V^T copy of
+    the last vt_cols columns (vt_cols, ld) or None); resid = fp32 (M, N) -> updated in place (resid += A.W^T + bias), returned."""
+    lib = load_library()
+    M, K = A.shape
+    N = W.shape[0]
+    if resid is not None:
+        _check(lib.vx_op_gemm_rows(1, _ptr(A), _ptr(W), _ptr(bias), _ptr(resid), M, N, K, 0, None, 0, 0, current_stream_ptr(A.device)))
+        return resid
+    Cm = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    ld = (M + 255) // 256 * 256
+    vt = torch.zeros((vt_cols, ld), dtype=torch.bfloat16, device=A.device) if vt_cols else None
+    _check(lib.vx_op_gemm_rows(0, _ptr(A), _ptr(W), _ptr(bias), _ptr(Cm), M, N, K, int(relu), _ptr(vt), N - vt_cols, ld,
+                               current_stream_ptr(A.device)))
+    return Cm, vt
 
 
 def op_gemm_mx(A, W, bias=None, relu=False, out_mx=False, return_quant=False):
