@@ -354,7 +354,7 @@ def run_rank(args) -> int:
             fp8 = args.precision == "fp8nar"
             peak = 5000.0 if fp8 else 2500.0  # MI355X_MICROARCH.md: dense fp8 / bf16 MFMA peak, TFLOP/s
             tf = g_fl / (g_ms * 1e-3) / 1e12
-            gemm = {"bound": "mfma", "kernel": ("NAR stage GEMMs on MXFP8 (QKV, FFN1, FFN2: mx256_kernel)" if fp8 else
+            gemm = {"bound": "mfma", "kernel": ("NAR stage GEMMs on MXFP8 (QKV, FFN1, FFN2: mx256p_kernel)" if fp8 else
                                                   "NAR stage GEMMs in bf16 (QKV, out-projection, FFN1, FFN2: mfma256p_kernel)"),
                     "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
                     "flops_per_launch": int(g_fl / max(1, len(tms))), "ms_per_launch": round(g_ms / max(1, len(tms)), 3),

@@ -211,8 +211,8 @@ int vx_op_gemm(int32_t prec, int32_t use_mfma, const void* A, const void* W, con
                int32_t M, int32_t N, int32_t K, int32_t relu, void* stream);
 /* The bf16 MFMA GEMM in the forms the engine's row path launches (mfma_gemm_dispatch; reference op: F.linear inside
  * valle/modules/transformer.py:296-334): form 0: C (M, N) bf16 = A.W^T + bias [ReLU] (QKV / FFN1), optionally with the last
- * N - vt_n0 columns also written transposed to vt (N - vt_n0, vt_ld) bf16 (the V^T copy the attention kernel reads; vt may be
- * NULL); form 1: C (M, N) fp32 += A.W^T + bias (out-projection / FFN2 onto the residual stream). */
+ * N - vt_n0 columns (vt_n0 a multiple of 64) also written transposed to vt (N - vt_n0, vt_ld) bf16 (the V^T copy the attention
+ * kernel reads; vt may be NULL); form 1: C (M, N) fp32 += A.W^T + bias (out-projection / FFN2 onto the residual stream). */
 int vx_op_gemm_rows(int32_t form, const void* A_bf16, const void* W_bf16, const float* bias, void* C, int32_t M, int32_t N,
                     int32_t K, int32_t relu, void* vt_bf16, int32_t vt_n0, int32_t vt_ld, void* stream);
 /* The MXFP8 (VX_PREC_FP8_NAR) kernels on caller data.  vx_op_gemm_mx: A (M, K) / W (N, K) fp32 device pointers are quantised

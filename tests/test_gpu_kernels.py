@@ -120,9 +120,10 @@ def test_gemm_rows_forms(eng, M, N, K):
     b = torch.randn(N, generator=g).cuda()
     ref = F.linear(A.double(), W.double(), b.double())
     scale = max(1.0, float(ref.abs().max()))
-    C, vt = eng.op_gemm_rows(A, W, b, vt_cols=N // 3)
+    vc = N // 3 // 64 * 64 + (N % 64)  # the copy starts at a multiple of 64 columns (the engine's is 2 d)
+    C, vt = eng.op_gemm_rows(A, W, b, vt_cols=vc)
     assert (C.double() - ref).abs().max() <= 2 ** -8 * scale  # one bf16 rounding of an fp32 sum
-    assert torch.equal(vt[:, :M], C[:, N - N // 3:].t())  # the transposed copy holds the same bf16 values
+    assert torch.equal(vt[:, :M], C[:, N - vc:].t())  # the transposed copy holds the same bf16 values
     Cr, _ = eng.op_gemm_rows(A, W, b, relu=True)
     assert (Cr.double() - ref.clamp_min(0)).abs().max() <= 2 ** -8 * scale
     X0 = torch.randn(M, N, generator=g).cuda()
@@ -201,7 +202,8 @@ def test_sampling_single_wave_variant_large_vocab(eng, top_k):
 
 
 # ---- MXFP8 kernels of VX_PREC_FP8_NAR (mx_kernels.hpp) against the host emulation of the same quantiser (tests/mx_ref.py) ----
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 1024), (4100, 3072, 1024), (513, 1024, 4096)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 1024), (4100, 3072, 1024), (513, 1024, 4096),
+                                   (20000, 1024, 512), (16700, 1280, 256)])  # the last two: more tiles than CUs (two per persistent workgroup)
 def test_mx_gemm_matches_host_emulation(eng, M, N, K):
     """Quantiser: bit-exact bytes and scales.  GEMM: both operands dequantise to exact fp32 values, so the matrix core's result
     differs from an fp64 evaluation of the same dequantised operands only by its internal accumulation: tolerance stated as a

@@ -2188,7 +2188,8 @@ extern "C" int vx_op_gemm_rows(int32_t form, const void* A, const void* Wp, cons
                                int32_t K, int32_t relu, void* vt, int32_t vt_n0, int32_t vt_ld, void* stream) {
   if (!A || !Wp || !C || !bias || M < 1 || N < 1 || K < 1) return fail(VX_ERR_ARG, "gemm_rows: null operand or empty shape");
   if (form != 0 && form != 1) return fail(VX_ERR_ARG, "gemm_rows: form %d", form);
-  if (vt && (form != 0 || vt_n0 < 0 || vt_n0 >= N || vt_ld < M)) return fail(VX_ERR_ARG, "gemm_rows: V^T copy needs form 0, 0 <= vt_n0 < N, vt_ld >= M");
+  if (vt && (form != 0 || vt_n0 < 0 || vt_n0 >= N || vt_n0 % 64 != 0 || vt_ld < M))
+    return fail(VX_ERR_ARG, "gemm_rows: V^T copy needs form 0, 0 <= vt_n0 < N, vt_n0 %% 64 == 0 (the kernels test whole column groups), vt_ld >= M");
   hipStream_t s = (hipStream_t)stream;
   if (mfma_gemm_dispatch((const bf16*)A, (const bf16*)Wp, bias, C, M, N, K, form == 1 ? GE_RESID : (relu ? GE_RELU : GE_BIAS), form == 1, s,
                          (bf16*)vt, vt_n0, vt_ld))

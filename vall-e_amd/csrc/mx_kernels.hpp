@@ -566,6 +566,387 @@ __global__ __launch_bounds__(512) void mx256w_kernel(const uint8_t* __restrict__
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stages issued past the last tile
 }
 
+// ---- the MXFP8 256x256 GEMM on the 8-phase ping-pong schedule of mfma256p_kernel (mfma_kernels.hpp): e4m3 rows of 128 k are 128
+// bytes, exactly a bf16 row of 64 k, so the byte geometry is the same - a K-tile (128 k) is four 16 KB half-tiles (B-h0, A-h0,
+// B-h1, A-h1) in one of two 64 KB buffers, one half-tile staged per phase with four in flight, the two row groups one barrier
+// apart - and so is the matrix time: a phase is one quadrant of the wave's 128 x 64 output over the K-tile's two 64-k steps =
+// 4 v_mfma_scale_f32_32x32x64_f8f6f4 of 64 cycles (bf16: 16 MFMAs of 16).  Fragment reads per phase 8 / 4 / 8 / 4 + the next
+// K-tile's four scale dwords.  The K-tile's 2 KB of E8M0 scales ([A | W][4 k-blocks][256 rows]) travel with its first half-tile:
+// wave w brings k-block w & 3 of operand w >> 2 with one 4-byte-per-lane LDS-DMA, so every wave issues nine loads per K-tile and
+// the counted wait is vmcnt(9).  Epilogues as in mx256_kernel; full tiles store unguarded (32 store instructions per lane, 40
+// with the scale bytes of the quantised form) so that the four waits behind an epilogue can count them in.
+// Three things this kernel needs that the bf16 one got away without (each seen in the ISA as 400-900 bytes of scratch per lane):
+// the stream's step to the next item is branch-free (a branch inside the phases splits the block); every phase ends with an empty
+// asm that uses its accumulators (the scaled MFMAs are pure and next used a K-tile later: the machine sinker moved them out of
+// their phases, all 32 to the bottom of the iteration); the fragment read addresses are rebuilt per phase from laundered lane
+// constants (held across the loop, eight XOR-ed variants per buffer were spilled).
+template <int EPI, int OUT>
+__global__ __launch_bounds__(512) void mx256p_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ SA, int lda_s,
+                                                     const uint8_t* __restrict__ W, const uint8_t* __restrict__ SW, int ldw_s,
+                                                     const float* __restrict__ bias, void* __restrict__ Cv,
+                                                     uint8_t* __restrict__ SC, int ldc_s, int M, int N, int K,
+                                                     bf16* __restrict__ vt, int vt_n0, int vt_ld, int ntn, int ntiles, P8Tail tl) {
+  constexpr int BUF = 65536 + 2048;  // four half-tiles | A scales 4 x 256 | W scales 4 x 256
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [2][BUF], then 8 x 256 B of bias values
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 31, h = lane >> 5;
+  const int G = gridDim.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  auto tile_of = [&](int v) {
+    const int xcd = v & 7, loc = v >> 3;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  };
+  const int nk = K >> 7;  // K-tiles of 128 k; K % 256 == 0: an even number
+  const int S = tl.split;
+  const int R = S > 1 ? ntiles / G : 0;
+  const bool has_tail = S > 1 && (int)blockIdx.x < (ntiles - R * G) * S;
+  const int cnt = S > 1 ? R + (has_tail ? 1 : 0) : (ntiles - (int)blockIdx.x + G - 1) / G;
+  const int tail_a = S > 1 ? (int)blockIdx.x / S : 0, tail_s = S > 1 ? (int)blockIdx.x - tail_a * S : 0;
+  auto item = [&](int ord, int& tile, int& kt0, int& kte) {
+    if (S > 1 && ord >= R) {
+      tile = tile_of(R * G + tail_a);
+      kt0 = tail_s * (nk / S);
+      kte = kt0 + nk / S;
+    } else {
+      tile = tile_of((int)blockIdx.x + ord * G);
+      kt0 = 0;
+      kte = nk;
+    }
+  };
+
+  // ---- load side (see mfma256p_kernel): two 16-byte slots per thread and half-tile, local row (tid >> 3) + 64 i, chunk swizzle
+  // position = chunk ^ ((row >> 1) & 7)
+  const int lrow = tid >> 3;
+  const unsigned csrc = (unsigned)(((tid & 7) ^ ((lrow >> 1) & 7)) * 16);
+  const unsigned ldst = (unsigned)(wave * 1024);
+  const unsigned tb = (unsigned)((lrow >> 5) * 64 + (lrow & 31));
+  const unsigned Kb = (unsigned)K;  // bytes per row
+  // The stream's item (first row, first column, K-tile, last K-tile + 1) and the one after it (n_*), all scalars.  The step to the
+  // next item is a handful of scalar selects: a branch inside the unrolled phases splits the block, and the machine sinker then
+  // moves the MFMAs out of their phase into the block of their next use (seen in the ISA: empty setprio pairs, 600 bytes of
+  // scratch).  The item after next is looked up once per output tile, outside the phases (set_next).
+  int l_kt = 0, l_kend = 0, l_m0 = 0, l_n0 = 0, n_kt = 0, n_kend = 0, n_m0 = 0, n_n0 = 0;
+  auto lookup = [&](int ord, int& m0_, int& n0_, int& kt_, int& kend_) {
+    int tile;
+    item(min(ord, cnt - 1), tile, kt_, kend_);  // past the end: the last item again (loaded, never used)
+    const int mt = tile / ntn;
+    m0_ = mt * 256;
+    n0_ = (tile - mt * ntn) * 256;
+  };
+  // kind 0: B-h0 (+ the K-tile's scales), 1: A-h0, 2: B-h1, 3: A-h1; kind 0 opens the next K-tile
+  auto stage = [&](auto kindc, auto bufc) {
+    constexpr int kind = decltype(kindc)::value, buf = decltype(bufc)::value;
+    constexpr bool isA = kind == 1 || kind == 3;
+    constexpr int sub = kind < 2 ? 0 : 1;
+    if (kind == 0) {
+      const bool adv = l_kt + 1 == l_kend;
+      l_kt = adv ? n_kt : l_kt + 1;
+      l_m0 = adv ? n_m0 : l_m0;
+      l_n0 = adv ? n_n0 : l_n0;
+      l_kend = adv ? n_kend : l_kend;
+    }
+    unsigned char* base = lds + buf * BUF + kind * 16384 + ldst;
+    const unsigned kb = (unsigned)l_kt * 128u + csrc;
+    unsigned o0, o1;
+    if (isA) {
+      const int row = l_m0 + lrow + 64 * sub;
+      o0 = (unsigned)min(row, M - 1) * Kb + kb;
+      o1 = (unsigned)min(row + 128, M - 1) * Kb + kb;
+    } else {
+      o0 = ((unsigned)(l_n0 + 32 * sub) + tb) * Kb + kb;
+      o1 = o0 + 128u * Kb;
+    }
+    const uint8_t* src = isA ? A : W;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)o0),
+                                     (__attribute__((address_space(3))) void*)(base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)o1),
+                                     (__attribute__((address_space(3))) void*)(base + 8192), 16, 0, 0);
+    if (kind == 0) {
+      // scales: wave w -> operand w >> 2, k-block w & 3 of this K-tile: 256 bytes = the tile's 256 rows (mx_spos order), 4 per lane
+      const uint8_t* sp = wave < 4 ? SA + (size_t)(4 * l_kt + wave) * lda_s + l_m0 : SW + (size_t)(4 * l_kt + wave - 4) * ldw_s + l_n0;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp + (unsigned)(lane * 4)),
+                                       (__attribute__((address_space(3))) void*)(lds + buf * BUF + 65536 + wave * 256), 4, 0, 0);
+    }
+  };
+
+  // ---- read side: lane (r = l & 31, h = l >> 5) reads, of row r of a 32-row fragment and 64-k step kk, chunk 4 kk + h (k-block
+  // 2 kk: operand bytes 0-15) and chunk 4 kk + 2 + h (k-block 2 kk + 1: bytes 16-31), and supplies the scale of k-block 2 kk + h
+  const unsigned pos0 = (unsigned)((h ^ ((r >> 1) & 7)) << 4);
+  const unsigned aoff = (unsigned)((wr * 64 + r) * 128), boff = (unsigned)((wc * 32 + r) * 128);
+  const unsigned soff = (unsigned)(h * 256 + r * 4);
+  f32x16_t acc[4][2];
+  i32x8_t fa[2][2], fb0[2], fb1[2];  // [fragment][kk]: the operand tuple is formed where it is read, once, not at each MFMA
+  auto ld8 = [](const unsigned char* p, unsigned o0, unsigned o1) {
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(p + o0), hi = *reinterpret_cast<const u32x4*>(p + o1);
+    i32x8_t v;
+    v[0] = (int)lo.x; v[1] = (int)lo.y; v[2] = (int)lo.z; v[3] = (int)lo.w;
+    v[4] = (int)hi.x; v[5] = (int)hi.y; v[6] = (int)hi.z; v[7] = (int)hi.w;
+    return v;
+  };
+  unsigned saX[2], swX[2], saY[2], swY[2];  // scale dwords per 64-k step of the even / odd K-tile
+  auto read_a = [&](auto bufc, auto subc) {
+    constexpr int buf = decltype(bufc)::value, sub = decltype(subc)::value;
+    unsigned ao = aoff, ps = pos0;  // rebuilt per phase: held across the loop, the read addresses of all buffers / blocks were spilled
+    asm volatile("" : "+v"(ao), "+v"(ps));
+    const unsigned pos0 = ps;
+    const unsigned char* b = lds + buf * BUF + (sub == 0 ? 1 : 3) * 16384 + ao;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fa[i][kk] = ld8(b + i * 4096, pos0 ^ ((4 * kk) << 4), pos0 ^ ((4 * kk + 2) << 4));
+  };
+  auto read_b = [&](auto bufc, auto subc, i32x8_t (&fb)[2]) {
+    constexpr int buf = decltype(bufc)::value, sub = decltype(subc)::value;
+    unsigned bo = boff, ps = pos0;
+    asm volatile("" : "+v"(bo), "+v"(ps));
+    const unsigned pos0 = ps;
+    const unsigned char* b = lds + buf * BUF + (sub == 0 ? 0 : 2) * 16384 + bo;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fb[kk] = ld8(b, pos0 ^ ((4 * kk) << 4), pos0 ^ ((4 * kk + 2) << 4));
+  };
+  auto read_s = [&](auto bufc, unsigned (&sa)[2], unsigned (&sw)[2]) {
+    constexpr int buf = decltype(bufc)::value;
+    unsigned so = soff;
+    asm volatile("" : "+v"(so));
+    const unsigned char* bs = lds + buf * BUF + 65536 + so;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      sa[kk] = *reinterpret_cast<const unsigned*>(bs + kk * 512 + wr * 128);
+      sw[kk] = *reinterpret_cast<const unsigned*>(bs + 1024 + kk * 512 + (wc >> 1) * 128) >> ((wc & 1) * 16);  // bytes 0, 1 = columns j = 0, 1
+    }
+  };
+  // quadrant (A-sub a, column fragment j) over the K-tile's two 64-k steps: 4 MFMAs; op_sel = byte of the scale dword
+  auto mm = [&](auto ac, auto jc, const i32x8_t (&fb)[2], const unsigned (&sa)[2], const unsigned (&sw)[2]) {
+    constexpr int a = decltype(ac)::value, j = decltype(jc)::value;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      acc[2 * a][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[kk], fa[0][kk], acc[2 * a][j], 0, 0, j, (int)sw[kk], 2 * a, (int)sa[kk]);
+      acc[2 * a + 1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[kk], fa[1][kk], acc[2 * a + 1][j], 0, 0, j, (int)sw[kk], 2 * a + 1, (int)sa[kk]);
+    }
+    // a use of the results inside the phase: without it the MFMAs (pure, next used a K-tile later) are sunk out of their phase
+    asm volatile("" : "+v"(acc[2 * a][j]), "+v"(acc[2 * a + 1][j]));
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  constexpr int NST = OUT == MX_OUT_MX ? 40 : 32;  // store instructions per lane of a full tile's epilogue
+  auto phase = [&](auto xc, auto laxc) {
+    constexpr int x = decltype(xc)::value;
+    constexpr bool lax = decltype(laxc)::value;
+    constexpr int p = x & 3;
+    constexpr bool odd = ((x >> 2) & 1) != 0;  // K-tile parity: buffer and scale register set
+    using CB = std::integral_constant<int, (x >> 2) & 1>;
+    using NB = std::integral_constant<int, ((x >> 2) & 1) ^ 1>;
+    using SK = std::integral_constant<int, (x + 2) & 3>;
+    using SB = std::integral_constant<int, ((x + 6) >> 2) & 1>;
+    if (p == 0) read_a(CB{}, I0{});
+    else if (p == 1) read_b(CB{}, I1{}, fb1);
+    else if (p == 2) read_a(CB{}, I1{});
+    else {
+      read_b(NB{}, I0{}, fb0);
+      if (odd) read_s(NB{}, saX, swX); else read_s(NB{}, saY, swY);
+    }
+    stage(SK{}, SB{});
+    if (lax) {
+      if (NST == 40) asm volatile("s_waitcnt vmcnt(50)\n\ts_barrier" ::: "memory");  // 9 operand loads + 40 stores + the bias load
+      else asm volatile("s_waitcnt vmcnt(42)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    if (!odd) {
+      if (p == 0) mm(I0{}, I0{}, fb0, saX, swX);
+      else if (p == 1) mm(I0{}, I1{}, fb1, saX, swX);
+      else if (p == 2) mm(I1{}, I0{}, fb0, saX, swX);
+      else mm(I1{}, I1{}, fb1, saX, swX);
+    } else {
+      if (p == 0) mm(I0{}, I0{}, fb0, saY, swY);
+      else if (p == 1) mm(I0{}, I1{}, fb1, saY, swY);
+      else if (p == 2) mm(I1{}, I0{}, fb0, saY, swY);
+      else mm(I1{}, I1{}, fb1, saY, swY);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
+  using P4 = std::integral_constant<int, 4>;
+  using P5 = std::integral_constant<int, 5>;
+  using P6 = std::integral_constant<int, 6>;
+  using P7 = std::integral_constant<int, 7>;
+
+  // prologue: events 0..5; events 0 (B-h0 + scales of K-tile 0) and 1 landed everywhere behind the barrier
+  lookup(0, l_m0, l_n0, l_kt, l_kend);
+  lookup(1, n_m0, n_n0, n_kt, n_kend);
+  --l_kt;
+  stage(I0{}, I0{});
+  stage(I1{}, I0{});
+  stage(I2{}, I0{});
+  stage(I3{}, I0{});
+  stage(I0{}, I1{});
+  stage(I1{}, I1{});
+  asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
+  read_b(I0{}, I0{}, fb0);
+  read_s(I0{}, saX, swX);
+  if (wr == 1) asm volatile("s_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  int lax = 0;
+  unsigned char* blds = lds + 2 * BUF + wave * 256;
+  for (int ord = 0; ord < cnt; ++ord) {
+    int tile, kt0, kte;
+    item(ord, tile, kt0, kte);
+    const bool is_tail = S > 1 && ord >= R;
+    // the stream is inside item `ord` now (it runs at most a K-tile and a half ahead and an item has at least two): its next is ord + 1
+    lookup(ord + 1, n_m0, n_n0, n_kt, n_kend);
+    const int mt = tile / ntn, nt = tile - mt * ntn;
+    const int m0 = mt * 256, n0 = nt * 256;
+    if (EPI != GE_PLAIN) {
+      unsigned l4 = (unsigned)lane * 4u;
+      asm volatile("" : "+v"(l4));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(bias + n0 + wc * 64) + l4),
+                                       (__attribute__((address_space(3))) void*)(blds), 4, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    if (lax) {
+      phase(P0{}, std::true_type{});
+      phase(P1{}, std::true_type{});
+      phase(P2{}, std::true_type{});
+      phase(P3{}, std::true_type{});
+    } else {
+      phase(P0{}, std::false_type{});
+      phase(P1{}, std::false_type{});
+      phase(P2{}, std::false_type{});
+      phase(P3{}, std::false_type{});
+    }
+    phase(P4{}, std::false_type{});
+    phase(P5{}, std::false_type{});
+    phase(P6{}, std::false_type{});
+    phase(P7{}, std::false_type{});
+    for (int t = kt0 + 2; t < kte; t += 2) {
+      phase(P0{}, std::false_type{});
+      phase(P1{}, std::false_type{});
+      phase(P2{}, std::false_type{});
+      phase(P3{}, std::false_type{});
+      phase(P4{}, std::false_type{});
+      phase(P5{}, std::false_type{});
+      phase(P6{}, std::false_type{});
+      phase(P7{}, std::false_type{});
+    }
+
+    // epilogue: acc[i][j][v] = C[m = m0 + wr*128 + i*32 + r][n = n0 + wc*64 + j*32 + (v&3) + 8*(v>>2) + 4*h]
+    const bool has_vt = OUT == MX_OUT_BF16 && vt != nullptr && n0 + 256 > vt_n0;
+    const bool full = m0 + 256 <= M;
+    unsigned hq = (unsigned)(h * 16);
+    asm volatile("" : "+v"(hq));
+    auto emit = [&](auto guardc) {
+      constexpr bool guard = decltype(guardc)::value;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nf = n0 + wc * 64 + j * 32;
+        f32x4v_t bq[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+          bq[qd] = EPI != GE_PLAIN ? *reinterpret_cast<const f32x4v_t*>(blds + hq + j * 128 + qd * 32) : f32x4v_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + wr * 128 + i * 32 + r;
+          float x[16];
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[4 * qd + e] = acc[i][j][4 * qd + e] + bq[qd][e];
+          if (EPI == GE_RELU) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) x[v] = fmaxf(x[v], 0.f);
+          }
+          if (OUT == MX_OUT_MX) {  // the row's 32 columns of this fragment are one MX block: 16 here, 16 in the other half-wave
+            float am = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) am = fmaxf(am, fabsf(x[v]));
+            am = fmaxf(am, xor32_f(am));
+            float inv;
+            const uint32_t sb = mx_block_scale(am, inv);
+            if (!guard || m < M) {
+              uint8_t* cp = reinterpret_cast<uint8_t*>(Cv) + (size_t)m * N + nf + 4 * h;
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd)
+                *reinterpret_cast<uint32_t*>(cp + 8 * qd) = mx_pack4(x[4 * qd], x[4 * qd + 1], x[4 * qd + 2], x[4 * qd + 3], inv);
+              if (h == 0) SC[(size_t)(nf >> 5) * ldc_s + mx_spos(m)] = (uint8_t)sb;
+            }
+          } else if (!guard || m < M) {
+            if (OUT == MX_OUT_F32) {
+              float* cp = reinterpret_cast<float*>(Cv) + (size_t)m * N + nf + 4 * h;
+              f32x4v_t old[4];
+              if (EPI == GE_RESID) {  // the four old values together behind one wait (see mfma256p_kernel)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(old[qd]) : "v"(cp + 8 * qd) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]) : : "memory");
+              }
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd) {
+                float4* p4 = reinterpret_cast<float4*>(cp + 8 * qd);
+                if (EPI == GE_RESID) *p4 = make_float4(old[qd][0] + x[4 * qd], old[qd][1] + x[4 * qd + 1], old[qd][2] + x[4 * qd + 2], old[qd][3] + x[4 * qd + 3]);
+                else *p4 = make_float4(x[4 * qd], x[4 * qd + 1], x[4 * qd + 2], x[4 * qd + 3]);
+              }
+            } else {
+              bf16* cp = reinterpret_cast<bf16*>(Cv) + (size_t)m * N + nf + 4 * h;
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd) {
+                union { bf16 e[4]; uint2 u; } pk;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pk.e[v] = (bf16)x[4 * qd + v];
+                *reinterpret_cast<uint2*>(cp + 8 * qd) = pk.u;
+                if (vt != nullptr && nf >= vt_n0) {
+#pragma unroll
+                  for (int v = 0; v < 4; ++v) vt[(size_t)(nf + 8 * qd + 4 * h + v - vt_n0) * vt_ld + m] = pk.e[v];
+                }
+              }
+            }
+          }
+        }
+      }
+    };
+    if (is_tail) {
+      // tail item (fp32 forms only): partial tile to the workspace, [item][256][256] fp32; p8_tail_reduce_kernel finishes it
+      unsigned lo = (unsigned)((r * 256 + 4 * h) * 4);
+      asm volatile("" : "+v"(lo));
+      unsigned char* slab = reinterpret_cast<unsigned char*>(tl.ws + (size_t)(tail_a * S + tail_s) * 65536 + wr * 32768 + wc * 64) + lo;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd)
+            *reinterpret_cast<f32x4v_t*>(slab + i * 32768 + j * 128 + qd * 32) =
+                f32x4v_t{acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
+      lax = 0;
+    } else if (full) {
+      emit(std::false_type{});
+      lax = __builtin_amdgcn_readfirstlane((has_vt || EPI == GE_RESID) ? 0 : 1);
+    } else {
+      emit(std::true_type{});
+      lax = 0;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wr == 0) asm volatile("s_barrier" ::: "memory");
+}
+
 // C = A . W^T on MXFP8 operands.  M any (rows clamped, scale arrays padded to 256 rows), N % 256 == 0, K % 128 == 0.
 static inline int mx_gemm_dispatch(const uint8_t* A, const uint8_t* SA, int lda_s, const uint8_t* W, const uint8_t* SW, int ldw_s,
                                    const float* bias, void* C, uint8_t* SC, int ldc_s, int M, int N, int K, int epi, int out,
@@ -581,7 +962,10 @@ static inline int mx_gemm_dispatch(const uint8_t* A, const uint8_t* SA, int lda_
   const int grid = ntn * ntm < ncu ? ntn * ntm : ncu;
   // default: the 64-byte-row ring kernel (mx256_kernel); VX_MX_ALG=0 selects the full-line kernel (mx256w_kernel).  A/B at
   // 117 k rows (profiles/r02_notes.md): 1335 vs 1350 TF/s - full 128-byte lines per LDS-DMA instruction buy nothing here
-  static const int alg = [] { const char* v = getenv("VX_MX_ALG"); return v ? atoi(v) : 1; }();
+  static const int alg = [] { const char* v = getenv("VX_MX_ALG"); return v ? atoi(v) : 2; }();  // 2: the 8-phase kernel (default), 1: the 32-k ring, 0: full-line staging
+  const bool p8 = alg == 2 && K % 256 == 0 && (size_t)M * K < 0xFFFF0000ull && (size_t)N * K < 0xFFFF0000ull;
+  // tail split (VX_GEMM_TAIL=1, fp32 forms only: the second launch's epilogue is the bf16 GEMM's); a K-tile here is 128 k
+  const P8Tail tl = (p8 && out == MX_OUT_F32) ? p8_tail_plan(ntn * ntm, grid, K / 2, s) : P8Tail{nullptr, 0};
 #define MX(E, O)                                                                                                         \
   do {                                                                                                                  \
     static bool attr_done = false;                                                                                      \
@@ -590,7 +974,18 @@ static inline int mx_gemm_dispatch(const uint8_t* A, const uint8_t* SA, int lda_
       (void)hipFuncSetAttribute((const void*)mx256w_kernel<E, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (65536 + 2048)); \
       attr_done = true;                                                                                                 \
     }                                                                                                                   \
-    if (alg == 1)                                                                                                       \
+    if (p8) {                                                                                                           \
+      static bool attr_p = false;                                                                                       \
+      if (!attr_p) {                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)mx256p_kernel<E, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (65536 + 2048) + 2048); \
+        attr_p = true;                                                                                                  \
+      }                                                                                                                 \
+      mx256p_kernel<E, O><<<grid, 512, 2 * (65536 + 2048) + 2048, s>>>(A, SA, lda_s, W, SW, ldw_s, bias, C, SC, ldc_s, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm, tl); \
+      if (tl.split > 1) {                                                                                               \
+        const int nt_all = ntn * ntm, rem_t = nt_all % grid;                                                            \
+        p8_tail_reduce_kernel<E, true><<<dim3(rem_t, 16), 256, 0, s>>>(tl.ws, tl.split, nt_all - rem_t, ntn, nt_all, bias, C, M, N, nullptr, 0, 0); \
+      }                                                                                                                 \
+    } else if (alg != 0)                                                                                                \
       mx256_kernel<E, O><<<grid, 512, 4 * (32768 + 1024), s>>>(A, SA, lda_s, W, SW, ldw_s, bias, C, SC, ldc_s, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);  \
     else                                                                                                                \
       mx256w_kernel<E, O><<<grid, 512, 2 * (65536 + 2048), s>>>(A, SA, lda_s, W, SW, ldw_s, bias, C, SC, ldc_s, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm); \
