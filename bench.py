@@ -267,6 +267,7 @@ def run_rank(args) -> int:
         mine = scatter_lists(lists, n_steps * Bt, dev, world, rank)
         outs, frames, tms, shapes = [], 0, [], []
         for i in range(n_steps):
+            t_step = time.perf_counter()
             group = mine[i * Bt : (i + 1) * Bt]
             seed0 = 1234 + ((first_step + i) * world + rank) * Bt
             if Bt > 1:
@@ -278,6 +279,10 @@ def run_rank(args) -> int:
             frames += sum(c.shape[1] for c in res)
             tms.append((eng or model).timings())
             shapes.append([(u[0].shape[1], u[2].shape[1], c.shape[1]) for u, c in zip(group, res)])
+            if os.environ.get("VX_BENCH_VERBOSE") and rank == 0:  # host wall time per step (includes what the device timers do not)
+                if not dry:
+                    torch.cuda.synchronize(dev)
+                print(f"bench.py: step {first_step + i}: {(time.perf_counter() - t_step) * 1e3:.2f} ms wall", file=sys.stderr)
         got = gather_lists(outs, dev, world, rank)
         ordered = None
         if got is not None:
