@@ -235,12 +235,9 @@ __global__ __launch_bounds__(256) void attn_batch_kernel(const float* __restrict
       sc[u] = (j < ctx) ? dot * scale : -INFINITY;
       mloc = fmaxf(mloc, sc[u]);
     }
-    mloc = wave_max_dpp(mloc);
-    __syncthreads();
-    if (lane == 0) sm_red[wave] = mloc;
-    __syncthreads();
-    const float mb = fmaxf(fmaxf(sm_red[0], sm_red[1]), fmaxf(sm_red[2], sm_red[3]));
-    const float Mn = fmaxf(M, mb);
+    // running maximum per WAVE (merged across the four waves once, at the end): a workgroup-wide maximum per pass cost two
+    // barriers per 128 keys, and with them the waves' loads and arithmetic stopped overlapping each other's
+    const float Mn = fmaxf(M, wave_max_dpp(mloc));
     const float corr = (M == -INFINITY) ? 0.f : expf(M - Mn);
     L *= corr;
 #pragma unroll
@@ -271,11 +268,22 @@ __global__ __launch_bounds__(256) void attn_batch_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < VEC; ++i) sm_o[gi][sub * VEC + i] = acc[i];
   if (sub == 0) sm_l[gi] = L;
+  if (lane == 0) sm_red[wave] = M;
   __syncthreads();
   if (tid < HD) {
+    // every wave scored at least one live key (ctx >= 1 and the first pass covers key 0 in wave 0; a wave whose keys were all past
+    // ctx has M = -inf, L = 0, acc = 0 and weight 0)
+    const float Ma = fmaxf(fmaxf(sm_red[0], sm_red[1]), fmaxf(sm_red[2], sm_red[3]));
     float o = 0.f, l = 0.f;
 #pragma unroll
-    for (int gidx = 0; gidx < 4 * KPW; ++gidx) { o += sm_o[gidx][tid]; l += sm_l[gidx]; }
+    for (int w = 0; w < 4; ++w) {
+      const float wgt = (sm_red[w] == -INFINITY) ? 0.f : expf(sm_red[w] - Ma);
+      float ow = 0.f, lw = 0.f;
+#pragma unroll
+      for (int gidx = 0; gidx < KPW; ++gidx) { ow += sm_o[w * KPW + gidx][tid]; lw += sm_l[w * KPW + gidx]; }
+      o = fmaf(wgt, ow, o);
+      l = fmaf(wgt, lw, l);
+    }
     out[(size_t)slot * d + h * HD + tid] = (bf16)(o / l);
   }
 }
