@@ -44,8 +44,23 @@ lib.vx_op_gemm.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_voi
 lib.vx_op_gemm_rows.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
 ld = (M + 255) // 256 * 256
 vt = dmalloc((N // 3) * ld * 2, 0) if form == "qkv" else None
+if form == "mx":  # MXFP8 GEMM (vx_op_gemm_mx quantises fp32 operands on the device, then mx256p_kernel): fp32 copies of the operands
+    import numpy as np
+
+    def dev_f32(n, seed, scale):
+        rng = np.random.default_rng(seed)
+        h = (rng.standard_normal(n, dtype=np.float32) * scale).astype(np.float32)
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(n * 4)) == 0
+        assert hip.hipMemcpy(p, h.ctypes.data_as(C.c_void_p), C.c_size_t(n * 4), 1) == 0
+        return p
+
+    Af, Wf = dev_f32(M * K, 3, 1.0), dev_f32(N * K, 4, K ** -0.5)
+    lib.vx_op_gemm_mx.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p] * 3
 for _ in range(iters):
-    if form == "f32":
+    if form == "mx":
+        rc = lib.vx_op_gemm_mx(Af, Wf, bias, Cm, None, M, N, K, 0, 0, None, None, None)
+    elif form == "f32":
         rc = lib.vx_op_gemm(1, 1, A, W, bias, Cm, M, N, K, 0, None)
     elif form == "resid":
         rc = lib.vx_op_gemm_rows(1, A, W, bias, Cm, M, N, K, 0, None, 0, 0, None)

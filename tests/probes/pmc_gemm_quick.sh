@@ -21,13 +21,13 @@ for d in sorted(glob.glob(sys.argv[1] + "/p*/")):
         print("no data", d, e); continue
     agg = collections.defaultdict(list)
     for r in rows:
-        if "gemm" in r["Kernel_Name"] or "mfma256" in r["Kernel_Name"]:
+        if ("gemm" in r["Kernel_Name"] or "mfma256" in r["Kernel_Name"] or "mx256" in r["Kernel_Name"]) and "quant" not in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             res["kernel"] = r["Kernel_Name"][:90]
     for k, v in agg.items():
         res[k] = sum(v) / len(v)
     kt = list(csv.DictReader(open(glob.glob(d + "**/*kernel_trace.csv", recursive=True)[0])))
-    durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in kt if "gemm" in r["Kernel_Name"] or "mfma256" in r["Kernel_Name"]]
+    durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in kt if ("gemm" in r["Kernel_Name"] or "mfma256" in r["Kernel_Name"] or "mx256" in r["Kernel_Name"]) and "quant" not in r["Kernel_Name"]]
     if durs: res.setdefault("dur_us", []).append(round(sum(durs) / len(durs) / 1e3, 1))
 if "SQ_VALU_MFMA_BUSY_CYCLES" in res and "GRBM_GUI_ACTIVE" in res:
     # GRBM_GUI_ACTIVE counts per XCD (8): chip-wide SIMD-cycles = GUI / 8 x 1024 SIMDs (r01_notes.md)
