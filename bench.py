@@ -375,6 +375,8 @@ def run_rank(args) -> int:
                 out["roofline"]["traffic"] = int(prof["gemv_bytes_per_step_corrected"] + prof["attn_bytes_per_ctx_row_corrected"] * ctx_mean)
                 out["roofline"]["traffic_source"] = (f"{src}: FETCH_SIZE x2 from a separate rocprofv3 --pmc pass of an eager (no-graph) run, "
                                                      "quoted at this run's mean context; NOT measured in this run")
+                if prof.get("write_bytes_per_step"):
+                    out["roofline"]["traffic_writes"] = int(prof["write_bytes_per_step"])  # WRITE_SIZE of the same collection
         if world == 1 and not args.no_cpu_baseline and not dry:
             x, x_lens, y = synthetic_inputs(S_TEXT, P_PROMPT, 8, seed=1)
             out["cpu_baseline"] = cpu_baseline(sd, cfg, x, x_lens, y, args.cpu_budget)
