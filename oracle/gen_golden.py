@@ -67,8 +67,11 @@ CASES = {
     "reftest_mode2_scale05_q6": (dict(decoder_dim=64, nhead=16, num_decoder_layers=4, prefix_mode=2, norm_first=False, add_prenet=True,
                                       scale_factor=0.5, num_quantizers=6), 8, 16, -100, 1.0, 53, 2, (0, 5)),
     "cfg1_topk10": (dict(decoder_dim=1024, nhead=16, num_decoder_layers=12, prefix_mode=1), 47, 225, 10, 1.0, 1234, None, (0, 1, 376, 752)),
+    # BASELINE.json configs[4]'s utterance: the cfg1 model, S=94 -> 1505 tokens (20 s) x 8 codebooks.  The no-cache reference is
+    # O(T^2): ~1 h of CPU on 8 threads; run with GOLDEN_NARSTATS=1 so that the per-stage NAR statistics come from the same pass
+    "cfg4_s94_topk10": (dict(decoder_dim=1024, nhead=16, num_decoder_layers=12, prefix_mode=1), 94, 225, 10, 1.0, 4321, None, (0, 1, 752, 1504)),
 }
-SMALL = [k for k in CASES if not k.startswith("cfg1")]
+SMALL = [k for k in CASES if not k.startswith(("cfg1", "cfg4"))]
 V = 1025
 
 
@@ -80,12 +83,17 @@ def run_case(name: str):
     enroll_x_lens = None if enroll is None else torch.tensor([enroll], dtype=torch.int32)
     ref = build_reference_model(cfg, sd)
 
-    ar_log, nar_log = [], {}
+    ar_log, nar_log, nar_full = [], {}, {}
+    want_stats = os.environ.get("GOLDEN_NARSTATS", "0") == "1"
     ref.ar_predict_layer.register_forward_hook(lambda m, i, o: ar_log.append(o.detach()[0].clone()))
     if cfg.num_quantizers > 1:
         # tied predict layers are distinct modules sharing a Parameter (valle.py:268-271)
+        def hook(m, i, o, si):
+            nar_log[si] = o.detach()[0, :8].clone()
+            if want_stats:
+                nar_full[si] = o.detach()[0].clone()
         for si, layer in enumerate(ref.nar_predict_layers):
-            layer.register_forward_hook(lambda m, i, o, si=si: nar_log.__setitem__(si, o.detach()[0, :8].clone()))
+            layer.register_forward_hook(lambda m, i, o, si=si: hook(m, i, o, si))
 
     if sseed is not None:
         torch.manual_seed(sseed)
@@ -136,6 +144,10 @@ def run_case(name: str):
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
     print(f"[{name}] wrote {os.path.getsize(os.path.join(OUT, name + '.npz')) / 1024:.0f} KiB", flush=True)
+    if want_stats and nar_full:
+        # the same record oracle/gen_nar_stats.py writes, from this pass's hooks (saves a second O(T^2) reference run)
+        from oracle.gen_nar_stats import write_stats
+        write_stats(name, codes, torch.stack([nar_full[i] for i in sorted(nar_full)]))
 
 
 def run_continual(name: str, prefix_mode: int, S: int, T: int, add_prenet: bool = False):

@@ -28,7 +28,6 @@ sys.dont_write_bytecode = True
 import valle_amd  # noqa: E402,F401
 from valle_amd.config import ModelConfig  # noqa: E402
 from valle_amd.weights import synthetic_inputs, synthetic_state_dict  # noqa: E402
-from oracle.gen_golden import CASES  # noqa: E402
 from oracle.ref_harness import build_reference_model  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "narstats")
@@ -37,6 +36,7 @@ N_ROWS = 16
 
 
 def run(name: str):
+    from oracle.gen_golden import CASES
     kw, S, P, top_k, temp, sseed, enroll, _ = CASES[name]
     cfg = ModelConfig(**kw)
     sd = synthetic_state_dict(cfg, seed=0)
@@ -54,8 +54,12 @@ def run(name: str):
     print(f"[{name}] reference {tuple(codes.shape)} in {time.time() - t0:.1f}s", flush=True)
     fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
     assert np.array_equal(fx["codes"].astype(np.int64), codes.numpy()), "reference run differs from the committed fixture"
+    write_stats(name, codes, torch.stack([logs[i] for i in sorted(logs)]))
+
+
+def write_stats(name: str, codes: torch.Tensor, st: torch.Tensor):
+    """st: (Q-1, T, 1024) logits of the reference's own nar_predict_layers."""
     T = codes.shape[1]
-    st = torch.stack([logs[i] for i in sorted(logs)])  # (Q-1, T, 1024)
     assert torch.equal(st.argmax(-1), codes[0, :, 1:].t())  # the reference's own argmax (valle.py:1130)
     top2 = st.topk(2, dim=-1)[0]
     rows = np.unique(np.linspace(0, T - 1, N_ROWS).round().astype(np.int64))
