@@ -468,6 +468,7 @@ struct SampleArgs {
   // batched decode: workgroup = slot; per-slot strides (0 in the batch-1 step, grid = 1)
   int logits_stride, tok_stride;
   int kid;  // probe builds: VX_KSTAMP id (-1 = not stamped)
+  unsigned* epoch;  // batch-1 step: launch counter, bumped once per step whatever the decode state (tags the hand-overs of ar_fused.hpp)
 };
 
 __device__ __forceinline__ uint32_t order_key(float v) {
@@ -697,6 +698,10 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
   float v[NVT], qn[NVT];
 #pragma unroll
   for (int j = 0; j < NVT; ++j) v[j] = lg[min(j * 256 + tid, V - 1)];
+  if (a.epoch != nullptr && tid == 0) {  // 0 is never a tag (fresh granules are zero-filled)
+    const unsigned n = *a.epoch + 1u;
+    *a.epoch = n ? n : 1u;
+  }
   if (st->done) return;  // uniform
   const int pass = st->pass;
 #ifdef VX_STAMPS

@@ -227,3 +227,26 @@ extern "C" int vx_debug_kstamps(void* dst, int64_t nbytes, int32_t* dims) {
   return fail(VX_ERR_UNSUPPORTED, "library built without -DVX_STAMPS (python vall-e_amd/csrc/build.py --stamps)");
 #endif
 }
+
+// Stamps build only: phase times of the fused QKV + attention launch (ar_fused.hpp FQ_STAMP), [layer 16][workgroup 256][8] uint64 of
+// s_memrealtime (100 MHz).  dst == NULL arms (allocates + zeroes), otherwise copies out.
+extern "C" int vx_debug_fqstamps(void* dst, int64_t nbytes) {
+#ifdef VX_STAMPS
+  static unsigned long long* buf = nullptr;
+  const size_t bytes = (size_t)2 * 16 * 256 * 16 * 8;  // [launch kind][layer][workgroup][16]
+  HIPC(hipDeviceSynchronize());
+  if (dst == nullptr) {
+    if (!buf) HIPC(hipMalloc((void**)&buf, bytes));
+    HIPC(hipMemset(buf, 0, bytes));
+    HIPC(hipMemcpyToSymbol(HIP_SYMBOL(g_fq_stamps), &buf, sizeof buf));
+    HIPC(hipDeviceSynchronize());
+    return VX_OK;
+  }
+  if (!buf) return fail(VX_ERR_STATE, "stamps not armed");
+  HIPC(hipMemcpy(dst, buf, (size_t)nbytes < bytes ? (size_t)nbytes : bytes, hipMemcpyDeviceToHost));
+  return VX_OK;
+#else
+  (void)dst; (void)nbytes;
+  return fail(VX_ERR_UNSUPPORTED, "library built without -DVX_STAMPS");
+#endif
+}
