@@ -12,6 +12,10 @@ sys.dont_write_bytecode = True
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The host oracle at test sizes (d <= 256) is a long chain of tiny matmuls: with the default intra-op pool on a shared box the
+# same GPU test took 4.5 s in one run and 42 s in the next (oversubscribed threads); four threads are as fast and steady.
+torch.set_num_threads(min(4, torch.get_num_threads()))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")

@@ -6,8 +6,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $out
 rocprofv3 -L 2>/dev/null | grep -o "SQC_ICACHE[A-Z_]*\|SQ_IFETCH[A-Z_]*\|SQ_WAIT_INST[A-Z_]*\|SQ_INSTS_VALU\b\|SQ_WAVE_CYCLES\|SQ_BUSY_CYCLES\|SQ_INST_CYCLES[A-Z_]*\|SQC_ICACHE_MISSES_DUPLICATE" | sort -u > $out/counters.txt
 cat $out/counters.txt
-for c in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU"; do
-  tag=$(echo $c | tr ' ' '+')
+for c in ${PMC_SETS:-"SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU"}; do
+  c=$(echo $c | tr ',' ' '); tag=$(echo $c | tr ' ' '+')
   timeout -k 10 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$tag -o g -- python3 tests/probes/pmc_driver.py $steps > $out/$tag.log 2>&1 || echo "pass $tag failed"
 done
 find $out -name "*kernel_trace.csv" -delete

@@ -38,7 +38,7 @@ for i in range(2):
     torch.manual_seed(1234 + i)
     m.inference(x, xl, y, None, top_k=10)
 NAMES = [["loads_issued", "ln_done", "qkv_published", "head_gathered", "partial_published", "partials_gathered", "out_stored", "row_arrived",
-          "att_start", "att_loop_done", "att_wave_merged", "att_barrier"],
+          "att_start", "att_loop_done", "att_wave_merged", "att_barrier", "x_arrived"],
          ["loads_issued", "ln_done", "hidden_published", "hidden_gathered", "out_stored", None, None, "row_arrived"]]
 res = {}
 for n_new in (100, 700):

@@ -15,7 +15,10 @@ from conftest import Golden, golden_names
 
 pytestmark = pytest.mark.gpu
 
-SMALL = [n for n in golden_names() if not n.startswith("cfg1")]
+SMALL = [n for n in golden_names() if not n.startswith(("cfg1", "cfg4"))]  # the full-size fixtures have tests of their own
+
+
+_BIG = {}  # d >= 1024 engines, shared across the tests of this module: the full-size fixtures use ONE model (weight seed 0)
 
 
 def _model(g, precision, **kw):
@@ -25,12 +28,21 @@ def _model(g, precision, **kw):
     from valle_amd.models import VALLE
 
     c = g.cfg
+    big = c.decoder_dim >= 1024
+    if big:  # one engine per (model, precision, options); logits tracing always on (7 MB)
+        kw.setdefault("trace_logits", True)
+        key = (repr(c), g.weight_seed, precision, tuple(sorted(kw.items())))
+        if key in _BIG:
+            return _BIG[key]
     m = VALLE(c.decoder_dim, c.nhead, c.num_decoder_layers, norm_first=c.norm_first, add_prenet=c.add_prenet, prefix_mode=c.prefix_mode,
               share_embedding=c.share_embedding,
               nar_scale_factor=c.scale_factor, prepend_bos=c.prepend_bos, num_quantizers=c.num_quantizers, precision=precision, max_text=128,
-              max_audio=1280, print_eos=False, **kw)
+              max_audio=1792 if big else 1280, print_eos=False, **kw)
     m.load_state_dict(g.state_dict())
-    return m.to("cuda:0").eval()
+    m = m.to("cuda:0").eval()
+    if big:
+        _BIG[key] = m
+    return m
 
 
 def _run(m, g, **kw):
@@ -54,12 +66,14 @@ def test_fp32_engine_reproduces_reference_codes(name):
         assert (got - g.nar_probe_logits[-1]).abs().max() <= 2e-3
 
 
-def test_fp32_engine_cfg1_full_length():
-    """BASELINE.json configs[1] geometry: d=1024 L=12, S=47, P=225 -> 753 frames x 8 codebooks, top-k 10."""
-    g = Golden("cfg1_topk10")
+@pytest.mark.parametrize("name,T", [("cfg1_topk10", 753), ("cfg4_s94_topk10", 1505)])
+def test_fp32_engine_full_length(name, T):
+    """BASELINE.json configs[1] geometry: d=1024 L=12, S=47, P=225 -> 753 frames x 8 codebooks, top-k 10; and configs[4]'s
+    utterance on the same model: S=94 -> 1505 frames (20 s), context 319 -> 1824 rows."""
+    g = Golden(name)
     m = _model(g, "fp32", trace_logits=True)
     codes = _run(m, g)
-    assert codes.shape == (1, 753, 8)
+    assert codes.shape == (1, T, 8)
     e = m.engine()
     for step, ref in zip(g.ar_probe_steps, g.ar_probe_logits):
         got = e.read("ar_logits", (1025,), offset_bytes=step * 1025 * 4)
@@ -67,6 +81,45 @@ def test_fp32_engine_cfg1_full_length():
     assert torch.equal(codes[..., 0], g.codes[..., 0])  # AR tokens: bit-exact over all 753 steps
     agree = (codes == g.codes).float().mean().item()
     assert agree == 1.0, f"NAR codes agreement {agree}"
+
+
+def test_sharded_step_matches_plain_step_beyond_one_key_pass(monkeypatch):
+    """The XCD-sharded decode step (ar_tp.hpp) keeps 16 x 128 cached keys per head in registers; a longer context takes further
+    passes with plain loads.  d=1024 / 16 heads / 2 layers in fp32, S=60, P=900, 1300 forced tokens: context 961 -> 2260 rows.
+    The sharded step and the plain five-launch step (VX_AR_TP=0 VX_AR_FUSED=0, itself pinned by every fixture) must give the
+    same logits at every traced pass up to summation order, and the same argmax wherever the margin exceeds that."""
+    from valle_amd.config import ModelConfig
+    from valle_amd.models import VALLE
+    from valle_amd.weights import synthetic_inputs, synthetic_state_dict
+
+    import __graft_entry__ as ge
+
+    ge.build()
+    cfg = ModelConfig(decoder_dim=1024, nhead=16, num_decoder_layers=2, prefix_mode=1)
+    sd = synthetic_state_dict(cfg, 3)
+    x, xl, y = synthetic_inputs(60, 900, 8, seed=9)
+    forced = torch.randint(0, 1024, (1300,), generator=torch.Generator().manual_seed(4))
+    rows = []
+    for tp in ("1", "0"):
+        monkeypatch.setenv("VX_AR_TP", tp)
+        monkeypatch.setenv("VX_AR_FUSED", tp)
+        m = VALLE(1024, 16, 2, prefix_mode=1, precision="fp32", max_text=64, max_audio=2304, print_eos=False, trace_logits=True)
+        m.load_state_dict(sd)
+        m.to("cuda:0").eval()
+        e = m.engine()
+        e.ar_prefill(x[0], y[0, :, 0].contiguous())
+        e.ar_decode(top_k=1, forced=forced)
+        toks, reason, n_pass = e.ar_result()
+        assert torch.equal(toks, forced) and n_pass == 1301
+        rows.append(e.read("ar_logits", (n_pass, 1025)).clone())
+        del e, m
+    a, b = rows
+    scale = b.abs().amax(1)
+    err = (a - b).abs().amax(1)
+    assert bool((err <= 2e-5 * scale + 1e-6).all()), float((err / scale).max())
+    top2 = b.topk(2, dim=1)[0]
+    decided = (top2[:, 0] - top2[:, 1]) > 4e-5 * scale
+    assert bool((a.argmax(1) == b.argmax(1))[decided].all())
 
 
 def test_graph_and_eager_steps_agree():
@@ -104,7 +157,8 @@ def test_torch_cpu_sampling_mode_follows_global_generator():
 
 @pytest.mark.parametrize("name,simple", [("cfg0_topk10", False), ("cfg0_topk10", True), ("tiny_mode0", False),
                                          ("tiny_mode2_q6", False), ("cfg0_postnorm", False), ("cfg0_postnorm", True),
-                                         ("cfg1_topk10", False), ("reftest_mode0", False), ("reftest_mode1_scale05_bos_q7", False)])
+                                         ("cfg1_topk10", False), ("cfg4_s94_topk10", False), ("reftest_mode0", False),
+                                         ("reftest_mode1_scale05_bos_q7", False)])
 def test_bf16_engine_teacher_forced(name, simple):
     from oracle import valle_oracle as vo
 
@@ -157,7 +211,7 @@ NAR_REL_TOL = 0.03  # bf16 operands through L layers, as a fraction of a logits 
 
 
 @pytest.mark.parametrize("name,precision", [("tiny_mode0", "fp32"), ("tiny_mode0", "bf16"), ("cfg0_topk10", "bf16"),
-                                            ("cfg1_topk10", "bf16")])
+                                            ("cfg1_topk10", "bf16"), ("cfg4_s94_topk10", "bf16")])
 def test_nar_stages_teacher_forced_margin_rule(name, precision):
     """North-star rule on the NAR side, for the precision the benchmark runs: every stage is fed the reference's own codes of
     the earlier stages (vx_nar_ex forced_codes: exactly the input the reference gave that stage, valle.py:1133-1134), so
@@ -198,10 +252,11 @@ def test_nar_stages_teacher_forced_margin_rule(name, precision):
         assert float(per_stage.min()) >= 0.95, per_stage
 
 
+FP8_AGREE_MIN = 0.88  # per-stage agreement with the reference's codes: measured 0.91-0.97 (d=1024), 0.90+ (d=256)
 FP8_REL_TOL = 0.08  # MXFP8 (e4m3, 3 mantissa bits, one power-of-two scale per 32 k) operands in the QKV / FFN GEMMs of 12 layers
 
 
-@pytest.mark.parametrize("name", ["cfg0_topk10", "cfg1_topk10"])
+@pytest.mark.parametrize("name", ["cfg0_topk10", "cfg1_topk10", "cfg4_s94_topk10"])
 def test_fp8_nar_stages_teacher_forced(name, monkeypatch):
     """VX_PREC_FP8_NAR (BASELINE configs[4]): the NAR stages' QKV / FFN1 / FFN2 GEMMs on MXFP8, everything else bf16.  Same
     protocol as the bf16 margin-rule test: every stage on the reference's inputs, logits of the recorded rows within the fp8
@@ -231,14 +286,14 @@ def test_fp8_nar_stages_teacher_forced(name, monkeypatch):
           "flipped decided rows %d" % int((~eq[decided]).sum()), "agreement per stage", [round(float(v), 4) for v in per_stage])
     assert worst <= FP8_REL_TOL
     assert bool(eq[decided].all()), f"{int((~eq[decided]).sum())} decided rows flipped"
-    assert float(per_stage.min()) >= 0.80, per_stage
+    assert float(per_stage.min()) >= FP8_AGREE_MIN, per_stage
     # the same utterance four times through the batched NAR (4352 concatenated rows: the product's MXFP8 path without the knob)
     monkeypatch.delenv("VX_MX_MIN_ROWS")
     if g.cfg.decoder_dim >= 1024:
         outs = e.nar_batch([text] * 4, [prompts] * 4, [ref[:, 0].contiguous()] * 4, forced_codes=[ref] * 4)
         for o in outs:
             eqb = (o.cpu()[:, 1:] == ref[:, 1:]).t()
-            assert bool(eqb[decided].all()) and float(eqb.float().mean(1).min()) >= 0.80
+            assert bool(eqb[decided].all()) and float(eqb.float().mean(1).min()) >= FP8_AGREE_MIN
 
 
 @pytest.mark.parametrize("name", golden_names("continual"))
@@ -574,6 +629,28 @@ def test_vallf_graph_and_eager_steps_agree():
     a = _run(_model_f(g, "fp32"), g)
     b = _run(_model_f(g, "fp32", no_graph=True), g)
     assert torch.equal(a, b) and torch.equal(a, g.codes)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_vallf_one_model_serves_texts_of_different_lengths(precision):
+    """valle/bin/infer.py loops over texts with ONE model; the decode step is captured once per engine.  The cross-attention
+    length must follow the current utterance (it is read from the decode state, not frozen into the captured launch): the
+    fixture's utterance (S = 7), then a longer text (S = 13), then a shorter one (S = 4), then the fixture again, each against
+    the oracle on the same model (fp32: bit-exact codes; bf16: identical to a fresh engine's, i.e. no state leaks across calls)."""
+    from oracle import valle_oracle as vo
+    from valle_amd.weights import synthetic_inputs
+
+    g = Golden("vallf_mode1")
+    m = _model_f(g, precision)
+    om = g.oracle()
+    utts = [(g.x, g.x_lens, g.y), synthetic_inputs(13, 9, 8, seed=77), synthetic_inputs(4, 21, 8, seed=78), (g.x, g.x_lens, g.y)]
+    for i, (x, xl, y) in enumerate(utts):
+        got = m.inference(x.cuda(), xl.cuda(), y.cuda(), None, top_k=1).cpu()
+        if precision == "fp32":
+            want = vo.inference_f(om, x, xl, y, None, 1, 1.0, None)
+        else:
+            want = _model_f(g, precision).inference(x.cuda(), xl.cuda(), y.cuda(), None, top_k=1).cpu()
+        assert torch.equal(got, want), i
 
 
 @pytest.mark.parametrize("name,simple", [("vallf_cfg0_topk10", False), ("vallf_cfg0_topk10", True), ("vallf_postnorm_mode4_bos", False),

@@ -74,13 +74,28 @@ def test_gemm_bf16(eng, M, N, K, mfma):
     assert (outr - ref.clamp_min(0)).abs().max() <= 2e-4 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("M,N,K", [(16500, 1024, 1024), (16400, 1280, 128), (20000, 768, 384), (66000, 256, 256),
-                                   (34700, 1024, 4096), (66000, 1024, 2048)])  # the last two: tail tiles split 8 / 4 ways along K
-@pytest.mark.parametrize("p8", ["1", "0"])
-def test_gemm_bf16_persistent_256_tiles(M, N, K, p8):
+@pytest.mark.parametrize("M,N,K", [(16500, 1024, 1024), (16400, 1280, 128), (20000, 768, 384), (66000, 256, 256), (34700, 1024, 4096),
+                                   (16500, 1024, 192), (20000, 512, 320)])  # the last two: K % 128 = 64 -> the 32-k ring kernel (mfma256_kernel)
+def test_gemm_bf16_persistent_256_tiles(eng, M, N, K):
     """More 256^2 tiles than CUs: every persistent workgroup walks two or more tiles (operand stream running on across the tile
-    boundary, counted waits behind an epilogue's stores, ragged last row tile), for the 8-phase kernel and the 32-k ring
-    (VX_GEMM_P8 is read once per process: a child process per setting)."""
+    boundary, counted waits behind an epilogue's stores, ragged last row tile) - the 8-phase kernel, and the 32-k ring that serves
+    the K it cannot take.  Reference: fp64 products of the same bf16 values."""
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    ref = F.linear(A.double(), W.double(), b.double()).float()
+    for relu in (False, True):
+        out = eng.op_gemm(A, W, b, relu=relu, mfma=True)
+        r = ref.clamp_min(0) if relu else ref
+        err = float((out - r).abs().max())
+        assert err <= 2e-4 * max(1.0, float(r.abs().max())), (relu, err)
+    assert torch.equal(eng.op_gemm(A, W, b, mfma=True), eng.op_gemm(A, W, b, mfma=True))  # bitwise reproducible
+
+
+def test_gemm_bf16_tail_split():
+    """VX_GEMM_TAIL=1 (off by default: position-dependent rounding): the last, mostly idle round of 256^2 tiles is split 8 / 4 ways
+    along K and summed by a second launch.  The switch is read once per process: one child process, both shapes."""
     import subprocess, sys, os
     from conftest import ROOT
 
@@ -90,22 +105,22 @@ sys.path.insert(0, {ROOT!r})
 import __graft_entry__ as ge
 ge.build()
 from valle_amd import engine as E
-g = torch.Generator().manual_seed(5)
-A = torch.randn({M}, {K}, generator=g).to(torch.bfloat16).cuda()
-W = (torch.randn({N}, {K}, generator=g) * {K} ** -0.5).to(torch.bfloat16).cuda()
-b = torch.randn({N}, generator=g).cuda()
-ref = torch.nn.functional.linear(A.double(), W.double(), b.double()).float()
-for relu in (False, True):
-    out = E.op_gemm(A, W, b, relu=relu, mfma=True)
-    r = ref.clamp_min(0) if relu else ref
-    err = float((out - r).abs().max())
-    assert err <= 2e-4 * max(1.0, float(r.abs().max())), (relu, err)
-out2 = E.op_gemm(A, W, b, mfma=True)
-assert torch.equal(out2, E.op_gemm(A, W, b, mfma=True))
+for M, N, K in ((34700, 1024, 4096), (66000, 1024, 2048)):
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    ref = torch.nn.functional.linear(A.double(), W.double(), b.double()).float()
+    for relu in (False, True):
+        out = E.op_gemm(A, W, b, relu=relu, mfma=True)
+        r = ref.clamp_min(0) if relu else ref
+        err = float((out - r).abs().max())
+        assert err <= 2e-4 * max(1.0, float(r.abs().max())), (M, relu, err)
+    assert torch.equal(E.op_gemm(A, W, b, mfma=True), E.op_gemm(A, W, b, mfma=True))
+    del A, W, b, ref
 print("ok")
 """
-    env = dict(os.environ, VX_GEMM_P8=p8, VX_GEMM_TAIL="1")  # the tail split is off by default (position-dependent rounding)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VX_GEMM_TAIL="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
@@ -203,7 +218,8 @@ def test_sampling_single_wave_variant_large_vocab(eng, top_k):
 
 # ---- MXFP8 kernels of VX_PREC_FP8_NAR (mx_kernels.hpp) against the host emulation of the same quantiser (tests/mx_ref.py) ----
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 1024), (4100, 3072, 1024), (513, 1024, 4096),
-                                   (20000, 1024, 512), (16700, 1280, 256)])  # the last two: more tiles than CUs (two per persistent workgroup)
+                                   (20000, 1024, 512), (16700, 1280, 256),  # more tiles than CUs (two per persistent workgroup)
+                                   (17000, 1024, 384)])                      # K % 256 = 128: the 32-k ring kernel (mx256_kernel), two tiles per workgroup
 def test_mx_gemm_matches_host_emulation(eng, M, N, K):
     """Quantiser: bit-exact bytes and scales.  GEMM: both operands dequantise to exact fp32 values, so the matrix core's result
     differs from an fp64 evaluation of the same dequantised operands only by its internal accumulation: tolerance stated as a

@@ -327,7 +327,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
   const int h = blockIdx.x / ATT_NSPLIT, s = blockIdx.x - h * ATT_NSPLIT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPK, grp = lane / LPK;
-  const int ctx = fixed_ctx > 0 ? fixed_ctx : st->row + 1;  // fixed_ctx: cross-attention over the cached text memory (VALL-F)
+  // fixed_ctx != 0: cross-attention over the cached text memory (VALL-F).  Its length is read from the decode state (uploaded by
+  // every prefill), never taken by value: the step is captured ONCE per engine and replayed for every later utterance
+  const int ctx = fixed_ctx != 0 ? st->S : st->row + 1;
   const int chunk = (ctx + ATT_NSPLIT - 1) / ATT_NSPLIT;
   const int j0 = s * chunk, j1 = min(ctx, j0 + chunk);
   float qv[VEC];
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void attn_decode_small_kernel(const float* __r
   __shared__ float sm_o[256][HD + 1];
   const int h = blockIdx.x / ATT_NSPLIT, s = blockIdx.x - h * ATT_NSPLIT;
   const int tid = threadIdx.x;
-  const int ctx = fixed_ctx > 0 ? fixed_ctx : st->row + 1;
+  const int ctx = fixed_ctx != 0 ? st->S : st->row + 1;  // see attn_decode_kernel
   const int chunk = (ctx + ATT_NSPLIT - 1) / ATT_NSPLIT;
   const int j0 = s * chunk, j1 = min(ctx, j0 + chunk);
   float qv[HD], o[HD];
@@ -682,27 +684,17 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
 // Four-wave variant used by the decode step: the single-wave kernel above executes ~3000 instructions
 // serially; here thread t owns logits t, t+256, ... (NVT each) for the elementwise work and the four
 // block-level reductions, while wave 0 alone also holds all keys (NV0 per lane) for the exact top-k select.
+// Body of the four-wave sampler.  v[j] = logit j * 256 + tid (any value past V), `lg` = the whole row for wave 0's exact top-k
+// select (global memory in the stand-alone kernel, LDS when the predict-layer launch samples in place, ar_tp.hpp).
 template <int NVT, int NV0>
-__global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) {
+__device__ __forceinline__ void sample4_body(const SampleArgs& a, ArState* st, float (&v)[NVT], const float* lg, int slot) {
   __shared__ float s_av[4], s_sv[4], s_f[4];
   __shared__ int s_ai[4], s_si[4];
   __shared__ uint32_t cand_lds[64];
   __shared__ uint32_t s_T;
-  const int slot = blockIdx.x;
-  ArState* st = a.st + slot;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = a.V;
-  // the newest logits row sits at a fixed address, so its loads go out together with the state loads instead of
-  // one round trip behind the `done` test
-  const float* lg = a.logits + (size_t)slot * a.logits_stride;
-  float v[NVT], qn[NVT];
-#pragma unroll
-  for (int j = 0; j < NVT; ++j) v[j] = lg[min(j * 256 + tid, V - 1)];
-  if (a.epoch != nullptr && tid == 0) {  // 0 is never a tag (fresh granules are zero-filled)
-    const unsigned n = *a.epoch + 1u;
-    *a.epoch = n ? n : 1u;
-  }
-  if (st->done) return;  // uniform
+  float qn[NVT];
   const int pass = st->pass;
 #ifdef VX_STAMPS
   const unsigned long long vx_t0 = __builtin_amdgcn_s_memrealtime();
@@ -834,6 +826,29 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
 #ifdef VX_STAMPS
   VX_KSTAMP_SELF(a.kid, pass + 1, vx_t0);  // slot = the pass index every later kernel of this step reads
 #endif
+}
+
+// Four-wave variant used by the decode step: the single-wave kernel above executes ~3000 instructions
+// serially; here thread t owns logits t, t+256, ... (NVT each) for the elementwise work and the four
+// block-level reductions, while wave 0 alone also holds all keys (NV0 per lane) for the exact top-k select.
+template <int NVT, int NV0>
+__global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) {
+  const int slot = blockIdx.x;
+  ArState* st = a.st + slot;
+  const int tid = threadIdx.x;
+  const int V = a.V;
+  // the newest logits row sits at a fixed address, so its loads go out together with the state loads instead of
+  // one round trip behind the `done` test
+  const float* lg = a.logits + (size_t)slot * a.logits_stride;
+  float v[NVT];
+#pragma unroll
+  for (int j = 0; j < NVT; ++j) v[j] = lg[min(j * 256 + tid, V - 1)];
+  if (a.epoch != nullptr && tid == 0) {  // 0 is never a tag (fresh granules are zero-filled)
+    const unsigned n = *a.epoch + 1u;
+    *a.epoch = n ? n : 1u;
+  }
+  if (st->done) return;  // uniform
+  sample4_body<NVT, NV0>(a, st, v, lg, slot);
 }
 
 }  // namespace vx

@@ -89,6 +89,10 @@ typedef float tp_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void tp_ld16(vx_u32x4& v, const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
 }
+// the weight stream (non-temporal loads measured: no difference, profiles/r03_notes.md)
+__device__ __forceinline__ void tp_ld16w(vx_u32x4& v, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+}
 __device__ __forceinline__ void tp_ld16f(tp_f4& v, const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
 }
@@ -104,19 +108,25 @@ struct TpRowLoads { tp_f4 x, b, g, be, p[TP_X]; };
 template <bool PARTS>
 __device__ __forceinline__ void tp_row_issue(TpRowLoads& r, const float* __restrict__ x_in, const float* __restrict__ part,
                                              const float* __restrict__ gbb, int tid) {
+#ifdef TP_EXP_STATIC_FIRST  // timing experiment: the static norm parameters first, the freshly written vectors behind them
+  tp_ld16f(r.g, gbb + 4 * tid);
+  tp_ld16f(r.be, gbb + TP_D + 4 * tid);
   tp_ld16f(r.x, x_in + 4 * tid);
   if (PARTS) {
-#ifdef TP_EXP_ONEPART  // timing experiment (wrong results): what do the eight partial rows cost?
-#pragma unroll
-    for (int s = 0; s < TP_X; ++s) tp_ld16f(r.p[s], part + 4 * tid);
-#else
 #pragma unroll
     for (int s = 0; s < TP_X; ++s) tp_ld16f(r.p[s], part + (size_t)s * TP_D + 4 * tid);
-#endif
+    tp_ld16f(r.b, gbb + 2 * TP_D + 4 * tid);
+  }
+#else
+  tp_ld16f(r.x, x_in + 4 * tid);
+  if (PARTS) {
+#pragma unroll
+    for (int s = 0; s < TP_X; ++s) tp_ld16f(r.p[s], part + (size_t)s * TP_D + 4 * tid);
     tp_ld16f(r.b, gbb + 2 * TP_D + 4 * tid);
   }
   tp_ld16f(r.g, gbb + 4 * tid);
   tp_ld16f(r.be, gbb + TP_D + 4 * tid);
+#endif
 }
 // AFTER = loads issued behind the row's
 template <bool PARTS, int AFTER> __device__ __forceinline__ void tp_row_wait(TpRowLoads& r) {
@@ -218,36 +228,40 @@ __global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ W
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int c = 0; c < KCH; ++c) tp_ld16(w[r][c], W + (size_t)(r * TP_D + ch) * TP_D + (c * 64 + lane) * VEC);
+    for (int c = 0; c < KCH; ++c) tp_ld16w(w[r][c], W + (size_t)(r * TP_D + ch) * TP_D + (c * 64 + lane) * VEC);
   float e_bias;
   {
     const float* bp = a.qkv_bias;  // first use of the by-value argument struct: its kernarg wait belongs HERE, behind the loads above
     asm volatile("" : "+s"(bp));
     tp_ld4f(e_bias, bp + min(lane, 2) * TP_D + ch);
   }
-  vx_u32x4 wo[OCH];
-  {
-    const uint4* wb = reinterpret_cast<const uint4*>(Wo_) + (size_t)(x * TP_WG + i) * OCH * 256;
-#pragma unroll
-    for (int m = 0; m < OCH; ++m) tp_ld16(wo[m], wb + m * 256 + tid);
-  }
+  // second-stage operands: the out-projection slice and this split's cached keys
   const int n_old = st_row;  // the newest row travels in the granules
   const int chunk = (n_old + FQ_G - 1) / FQ_G;
   const int j0 = j * chunk, j1 = min(n_old, j0 + chunk);
   const int sub = lane % LPK, grp = lane / LPK;
-  const void* kcp = a.kcache;
-  const void* vcp = a.vcache;
-  int ctxm = a.ctx_max;
-  asm volatile("" : "+s"(kcp), "+s"(vcp), "+s"(ctxm));
-  const WT* kb = reinterpret_cast<const WT*>(kcp) + (size_t)h * ctxm * HD + sub * VEC;
-  const WT* vb = reinterpret_cast<const WT*>(vcp) + (size_t)h * ctxm * HD + sub * VEC;
+  vx_u32x4 wo[OCH];
   vx_u32x4 kr[UNR], vr[UNR];
+  const WT* kb;
+  const WT* vb;
+  auto tp_stage2 = [&]() {
+    const uint4* wb = reinterpret_cast<const uint4*>(Wo_) + (size_t)(x * TP_WG + i) * OCH * 256;
 #pragma unroll
-  for (int u = 0; u < UNR; ++u) {
-    const int jk = min(j0 + u * KPB + wave * KPW + grp, max(n_old, 1) - 1);  // clamped: row 0 always exists
-    tp_ld16(kr[u], kb + (size_t)jk * HD);
-    tp_ld16(vr[u], vb + (size_t)jk * HD);
-  }
+    for (int m = 0; m < OCH; ++m) tp_ld16w(wo[m], wb + m * 256 + tid);
+    const void* kcp = a.kcache;
+    const void* vcp = a.vcache;
+    int ctxm = a.ctx_max;
+    asm volatile("" : "+s"(kcp), "+s"(vcp), "+s"(ctxm));
+    kb = reinterpret_cast<const WT*>(kcp) + (size_t)h * ctxm * HD + sub * VEC;
+    vb = reinterpret_cast<const WT*>(vcp) + (size_t)h * ctxm * HD + sub * VEC;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int jk = min(j0 + u * KPB + wave * KPW + grp, max(n_old, 1) - 1);  // clamped: row 0 always exists
+      tp_ld16(kr[u], kb + (size_t)jk * HD);
+      tp_ld16(vr[u], vb + (size_t)jk * HD);
+    }
+  };
+  tp_stage2();
   auto load_pass = [&](int base) {  // later passes of a long context (> 16 * UNR * KPB rows): plain loads
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -260,6 +274,13 @@ __global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ W
   constexpr int N_KV = 2 * UNR, N_WO = OCH, N_W = 3 * KCH;
 
   // ---- LN1, the three dot products, publish ----
+#ifdef VX_STAMPS
+#ifdef TP_EXP_STATIC_FIRST
+  if (PARTS) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rl.g) : "n"(11 + N_W + 1 + N_WO + N_KV) : "memory"); TP_STAMP(0, 12); }
+#else
+  if (PARTS) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rl.x) : "n"(11 + N_W + 1 + N_WO + N_KV) : "memory"); TP_STAMP(0, 12); }
+#endif
+#endif
   tp_row_wait<PARTS, N_W + 1 + N_WO + N_KV>(rl);
   TP_STAMP(0, 7);
   tp_row_norm<PARTS>(rl, a.row, xs, red, tid);
@@ -471,7 +492,7 @@ __global__ __launch_bounds__(256) void tp_ffn_kernel(const void* __restrict__ W1
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c = 0; c < KCH; ++c) tp_ld16(w1[r][c], W1 + (size_t)(row0 + r) * TP_D + (c * 64 + lane) * VEC);
+    for (int c = 0; c < KCH; ++c) tp_ld16w(w1[r][c], W1 + (size_t)(row0 + r) * TP_D + (c * 64 + lane) * VEC);
   float e_b1;
   {
     const float* bp = a.b1;  // first use of the by-value argument struct: its kernarg wait belongs HERE
@@ -479,12 +500,12 @@ __global__ __launch_bounds__(256) void tp_ffn_kernel(const void* __restrict__ W1
     tp_ld4f(e_b1, bp + row0 + min(lane, 3));
   }
   vx_u32x4 w2[FCH];
-  {
+  auto tp_stage2 = [&]() {
     const uint4* wb = reinterpret_cast<const uint4*>(W2_) + (size_t)(x * TP_WG + i) * FCH * 256;
 #pragma unroll
-    for (int m = 0; m < FCH; ++m) tp_ld16(w2[m], wb + m * 256 + tid);
-  }
-
+    for (int m = 0; m < FCH; ++m) tp_ld16w(w2[m], wb + m * 256 + tid);
+  };
+  tp_stage2();
   tp_row_wait<true, 4 * KCH + 1 + FCH>(rl);
   TP_STAMP(1, 7);
   tp_row_norm<true>(rl, a.row, xs, red, tid);
@@ -551,7 +572,7 @@ __global__ __launch_bounds__(256) void tp_head_kernel(const void* __restrict__ W
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c = 0; c < KCH; ++c) tp_ld16(w[r][c], W + (size_t)min(row0 + r, a.N - 1) * TP_D + (c * 64 + lane) * VEC);
+    for (int c = 0; c < KCH; ++c) tp_ld16w(w[r][c], W + (size_t)min(row0 + r, a.N - 1) * TP_D + (c * 64 + lane) * VEC);
   const int st_pass = st->pass, st_trace = st->trace_logits, st_done = st->done;
   tp_row_wait<true, 4 * KCH>(rl);
   tp_row_norm<true>(rl, a.row, xs, red, tid);

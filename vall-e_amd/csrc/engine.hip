@@ -187,6 +187,8 @@ struct vx_engine {
   size_t gemm_ev_used = 0;
   double gemm_flops = 0, t_gemm = 0, gemm_flops_done = 0;
   std::vector<void*> allocs;
+  char* arena = nullptr;
+  size_t arena_used = 256, arena_cap = (size_t)4 << 20;  // no sub-block equals the base pointer (which `allocs` owns)
 };
 
 // VX_POISON=1 (tests): every fresh device allocation is filled with 0xFF bytes (NaN as bf16 / fp32, -1 as integers)
@@ -199,6 +201,25 @@ static bool poison_on() {
 // Every fill below goes to the engine's stream: `es` is a non-blocking stream, a null-stream hipMemset is not ordered with the
 // kernels enqueued on it right afterwards (a fill landing late would wipe rows the first kernels had already written).
 static int dalloc(vx_engine* e, void** p, size_t bytes) {
+  // small blocks (the decode step's vectors, states, per-site norm parameters) share ONE 4 MB block: one translation entry
+  // serves them all (each is touched by every workgroup of every launch of the step)
+  static const bool arena_on = !(getenv("VX_ARENA") && atoi(getenv("VX_ARENA")) == 0);
+  if (arena_on && bytes <= (64u << 10)) {
+    const size_t need = (bytes ? bytes : 16) + 255 & ~(size_t)255;
+    if (e->arena == nullptr) {
+      HIPC(hipMalloc((void**)&e->arena, e->arena_cap));
+      e->allocs.push_back(e->arena);
+    }
+    if (e->arena_used + need <= e->arena_cap) {
+      *p = e->arena + e->arena_used;
+      e->arena_used += need;
+      if (poison_on()) {
+        HIPC(hipMemsetAsync(*p, 0xFF, need, e->es));
+        HIPC(hipStreamSynchronize(e->es));
+      }
+      return VX_OK;
+    }
+  }
   HIPC(hipMalloc(p, bytes ? bytes : 16));
   if (poison_on()) {  // debug mode: also finished before anything on another stream (weight uploads) can touch the block
     HIPC(hipMemsetAsync(*p, 0xFF, bytes ? bytes : 16, e->es));
@@ -1416,22 +1437,28 @@ static int enqueue_ar_step_tp(vx_engine* e, hipStream_t s) {
   return VX_OK;
 }
 
-static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
-  if (e->vallf) return enqueue_ar_step_f(e, s);
+static SampleArgs step_sample_args(vx_engine* e) {
   const vx_config& c = e->cfg;
-  const int d = c.d_model, H = c.nhead, hd = d / H;
-  const bool post = c.flags & VX_FLAG_POST_NORM;
   SampleArgs sa{};
   sa.logits = e->ar_logits; sa.V = AR_VOCAB; sa.st = e->d_st;
   sa.tokens = e->d_tokens; sa.sampled = e->d_sampled; sa.argmaxes = e->d_argmax;
   sa.emb = W<float>(e, "ar_audio_embedding.word_embeddings.weight");
   sa.alpha = W<float>(e, "ar_audio_position.alpha");
-  sa.pe = e->pe_ar; sa.x = e->ar_x; sa.d = d;
-  const bool prenet = c.flags & VX_FLAG_PRENET;
-  if (prenet) { sa.alpha = e->d_zero; sa.x = e->ar_e; }  // raw embedding; the position is added after the prenet
+  sa.pe = e->pe_ar; sa.x = e->ar_x; sa.d = c.d_model;
+  if (c.flags & VX_FLAG_PRENET) { sa.alpha = e->d_zero; sa.x = e->ar_e; }  // raw embedding; the position is added after the prenet
   sa.kid = 0;  // stamp ids of the step (probe builds): 0 sampling, 1 + 5 l + {0 QKV, 1 attention, 2 out-proj, 3 FFN1, 4 FFN2}, 61 head
   sa.epoch = e->d_epoch;
+  return sa;
+}
+static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
+  if (e->vallf) return enqueue_ar_step_f(e, s);
+  const vx_config& c = e->cfg;
+  const int d = c.d_model, H = c.nhead, hd = d / H;
+  const bool post = c.flags & VX_FLAG_POST_NORM;
+  const SampleArgs sa = step_sample_args(e);
+  const bool prenet = c.flags & VX_FLAG_PRENET;
   sample_embed4_kernel<5, 17><<<1, 256, 0, s>>>(sa);
+  if (e->tp) return enqueue_ar_step_tp(e, s);
   if (prenet) {  // y_emb = ar_audio_prenet(E[tok]); x = y_emb + alpha * pe (valle.py:1013-1015): three fp32 GEMVs
     GemvArgs p0{}, p1{}, p2{};
     p0.st = p1.st = p2.st = e->d_st;
@@ -1465,7 +1492,6 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     const PfW& n = seq[(idx + pf_dist) % seq.size()];
     gemv_prefetch(a, n.W, n.N, n.K, e->bf16, e->num_cu);
   };
-  if (e->tp) return enqueue_ar_step_tp(e, s);
   for (int li = 0; li < c.num_layers; ++li) {
     const LayerW& l = e->ar_l[li];
     char* kc = (char*)e->kv + (size_t)li * kv_layer;
@@ -1630,7 +1656,7 @@ static int enqueue_ar_step_f(vx_engine* e, hipStream_t s) {
     q.gamma = post ? l.n1_g : l.n2_g; q.beta = post ? l.n1_b : l.n2_b;
     if (post) q.xnorm_out = e->ar_xn;
     VXC(launch_gemv(e->bf16, q, e->num_cu, s));
-    VXC(attend(xk, xv, c.max_text, e->mem_len));
+    VXC(attend(xk, xv, c.max_text, 1));  // length = ArState.S (the current utterance's text rows), read on the device
     GemvArgs co{};
     co.st = e->d_st; co.hd = hd; co.nhead = H; co.kid = -1;
     co.W = l.cout_w; co.bias = l.cout_b; co.part = e->ar_part; co.y = e->ar_x; co.N = d; co.K = d; co.pro = PRO_ATTN; co.epi = EPI_RESID;

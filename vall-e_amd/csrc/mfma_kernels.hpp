@@ -1086,156 +1086,6 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
   if (wr == 0) asm volatile("s_barrier" ::: "memory");  // every wave has passed the same number of barriers
 }
 
-// ---- the 256x256 GEMM with FULL-LINE staging (see mx256w_kernel in mx_kernels.hpp for the reasoning): a stage is 64 k = 128-byte
-// rows (two MFMA k-steps of 32), TWO LDS buffers of 64 KB, one LDS-DMA wave-instruction = 8 rows x one whole 128-byte line; chunk
-// swizzle position = chunk ^ ((row >> 1) & 7).  Per stage and wave: 8 LDS-DMA loads, 24 fragment reads, 64 MFMAs, one barrier.
-template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(512) void mfma256w_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
-                                                       const float* __restrict__ bias, void* __restrict__ Cv, int M, int N,
-                                                       int K, bf16* __restrict__ vt, int vt_n0, int vt_ld, int ntn,
-                                                       int ntiles) {
-  constexpr int STAGE = 65536;  // A 32 KB | W 32 KB
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int r = lane & 15, g = lane >> 4;
-  const int G = gridDim.x;
-  const int q8 = ntiles >> 3, r8 = ntiles & 7;
-  auto tile_of = [&](int v) {
-    const int xcd = v & 7, loc = v >> 3;
-    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-  };
-  const int cnt = (ntiles - (int)blockIdx.x + G - 1) / G;
-  // one operand stage = 2048 16-byte slots, 4 per thread: slot tid + 512 i -> row (tid >> 3) + 64 i, position tid & 7 holds source
-  // chunk (tid & 7) ^ ((row >> 1) & 7), the same chunk for all four
-  const int row0 = tid >> 3;
-  const int csrc = ((tid & 7) ^ ((row0 >> 1) & 7)) * 8;  // elements
-  const int dbase = (tid - lane) * 16;
-  const int nk = K / 64;
-  int ra[4], rw[4];
-  int l_ord = 0, l_k = 0, l_buf = 0;
-  auto set_load_tile = [&](int ord) {
-    const int tile = tile_of((int)blockIdx.x + min(ord, cnt - 1) * G);
-    const int mt = tile / ntn, nt = tile - mt * ntn;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = min(mt * 256 + row0 + 64 * i, M - 1);
-      rw[i] = min(nt * 256 + row0 + 64 * i, N - 1);
-    }
-  };
-  auto stage = [&]() {
-    unsigned char* base = lds + l_buf * STAGE;
-    const size_t k0 = (size_t)l_k * 64 + csrc;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)ra[i] * K + k0),
-                                       (__attribute__((address_space(3))) void*)(base + dbase + 8192 * i), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (size_t)rw[i] * K + k0),
-                                       (__attribute__((address_space(3))) void*)(base + 32768 + dbase + 8192 * i), 16, 0, 0);
-    l_buf ^= 1;
-    if (++l_k == nk) { l_k = 0; set_load_tile(++l_ord); }
-  };
-
-  f32x4v_t acc[8][4];
-  bf16x8_t fbA[4], faA[8], fbB[4], faB[8];
-  auto lread = [&](int buf, int ks, bf16x8_t (&fb)[4], bf16x8_t (&fa)[8]) {
-    const unsigned char* ba = lds + buf * STAGE;
-    const unsigned char* bw = ba + 32768;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = wn * 64 + j * 16 + r;
-      fb[j] = *reinterpret_cast<const bf16x8_t*>(bw + row * 128 + (((4 * ks + g) ^ ((row >> 1) & 7)) << 4));
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = wm * 128 + i * 16 + r;
-      fa[i] = *reinterpret_cast<const bf16x8_t*>(ba + row * 128 + (((4 * ks + g) ^ ((row >> 1) & 7)) << 4));
-    }
-  };
-  auto mm = [&](const bf16x8_t (&fb)[4], const bf16x8_t (&fa)[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-  };
-  auto interleave = [&]() {  // the 12 fragment reads of the other k-step spread between this k-step's 32 MFMAs
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
-    }
-  };
-
-  // Stage s lives in buffer s & 1: [issue stage s+1 into the other buffer] [k-step 0 MFMAs while k-step 1's fragments load]
-  // [this wave's loads of stage s+1 landed, its reads of stage s returned] [barrier] [k-step 1 MFMAs while the first fragments of
-  // stage s+1 load].
-  set_load_tile(0);
-  stage();
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  lread(0, 0, fbA, faA);
-  int cur = 0;
-  for (int ord = 0; ord < cnt; ++ord) {
-    const int tile = tile_of((int)blockIdx.x + ord * G);
-    const int mt = tile / ntn, nt = tile - mt * ntn;
-    const int m0 = mt * 256, n0 = nt * 256;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v_t{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < nk; ++t) {
-      stage();
-      lread(cur, 1, fbB, faB);
-      mm(fbA, faA);
-      interleave();
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      cur ^= 1;
-      lread(cur, 0, fbA, faA);
-      mm(fbB, faB);
-      interleave();
-    }
-
-    // epilogue: acc[i][j][v] = C[m = m0 + wm*128 + i*16 + r][n = n0 + wn*64 + j*16 + 4g + v]
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nb = n0 + wn * 64 + j * 16 + 4 * g;  // N % 256 == 0: always in range
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (EPI != GE_PLAIN) bv = *reinterpret_cast<const float4*>(bias + nb);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + r;
-        float x[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
-        if (EPI == GE_RELU) {
-#pragma unroll
-          for (int v = 0; v < 4; ++v) x[v] = fmaxf(x[v], 0.f);
-        }
-        if (m < M) {
-          if (OUT_F32) {
-            float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (size_t)m * N + nb);
-            if (EPI == GE_RESID) {
-              const float4 o = *cp;
-              *cp = make_float4(o.x + x[0], o.y + x[1], o.z + x[2], o.w + x[3]);
-            } else {
-              *cp = make_float4(x[0], x[1], x[2], x[3]);
-            }
-          } else {
-            union { bf16 e[4]; uint2 u; } pk;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) pk.e[v] = (bf16)x[v];
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(Cv) + (size_t)m * N + nb) = pk.u;
-            if (vt != nullptr && nb >= vt_n0) {
-#pragma unroll
-              for (int v = 0; v < 4; ++v) vt[(size_t)(nb + v - vt_n0) * vt_ld + m] = pk.e[v];
-            }
-          }
-        }
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stages issued past the last tile
-}
-
 // Main loop of the 128^2 kernel for a grid of `wgs` workgroups: the LDS-DMA ring with 64-k stages (128 KB of LDS, one workgroup
 // per CU) when the grid fits one round, the 32-k ring (64 KB, two per CU) otherwise.  VX_GEMM_RING = 0 / 32 / 64 forces the
 // register-staged loop / one ring for A/B runs.
@@ -1312,35 +1162,27 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
       return cu > 0 ? cu : 256;
     }();
     const int grid256 = ntn * ntm < ncu ? ntn * ntm : ncu;  // one persistent workgroup per CU (128 KB of LDS each)
-    // the 8-phase schedule (default) needs whole pairs of 64-k tiles and 32-bit byte offsets into A and W; VX_GEMM_P8=0: the 32-k ring
-    static const bool p8_on = [] { const char* v = getenv("VX_GEMM_P8"); return !(v && atoi(v) == 0); }();
-    static const bool p8_sched0 = [] { const char* v = getenv("VX_GEMM_P8"); return v && atoi(v) == 2; }();  // A/B: the 12/4/8/0 read schedule (f32 + bias form only)
-    const bool p8 = p8_on && K % 128 == 0 && (size_t)M * K * 2 < 0xFFFF0000ull && (size_t)N * K * 2 < 0xFFFF0000ull;
-    const P8Tail tl = (p8 && !p8_sched0) ? p8_tail_plan(ntn * ntm, grid256, K, s) : P8Tail{nullptr, 0};  // all forms; in this model only the K = 4096 one (FFN2) ever splits
-    static const bool ring256 = [] { const char* v = getenv("VX_GEMM_WIDE"); return !(v && atoi(v) != 0); }();  // VX_GEMM_WIDE=1: the full-line kernel (A/B)
+    // the 8-phase schedule needs whole pairs of 64-k tiles and 32-bit byte offsets into A and W; any other K or size runs the
+    // 32-k ring (mfma256_kernel)
+    const bool p8 = K % 128 == 0 && (size_t)M * K * 2 < 0xFFFF0000ull && (size_t)N * K * 2 < 0xFFFF0000ull;
+    const P8Tail tl = p8 ? p8_tail_plan(ntn * ntm, grid256, K, s) : P8Tail{nullptr, 0};  // all forms; in this model only the K = 4096 one (FFN2) ever splits
 #define M2(E, F)                                                                                                         \
   do {                                                                                                                  \
     static bool attr_done = false;                                                                                      \
     if (!attr_done) {                                                                                                   \
       (void)hipFuncSetAttribute((const void*)mfma256_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);  \
-      (void)hipFuncSetAttribute((const void*)mfma256w_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
       (void)hipFuncSetAttribute((const void*)mfma256p_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
-      (void)hipFuncSetAttribute((const void*)mfma256p_kernel<GE_BIAS, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
       (void)hipFuncSetAttribute((const void*)mfma256p_kernel<E, F, VX_P8_SCHED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
       attr_done = true;                                                                                                 \
     }                                                                                                                   \
-    if (p8 && p8_sched0 && E == GE_BIAS && F) {                                                                          \
-      mfma256p_kernel<GE_BIAS, true, 0><<<grid256, 512, 131072 + 2048, s>>>((const bf16*)A, (const bf16*)W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm, tl); \
-    } else if (p8 && tl.split > 1) {                                                                                     \
+    if (p8 && tl.split > 1) {                                                                                     \
       const int nt_all = ntn * ntm, rem_t = nt_all % grid256;                                                           \
       mfma256p_kernel<E, F, VX_P8_SCHED, true><<<grid256, 512, 131072 + 2048, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, nt_all, tl); \
       p8_tail_reduce_kernel<E, F><<<dim3(rem_t, 16), 256, 0, s>>>(tl.ws, tl.split, nt_all - rem_t, ntn, nt_all, bias, C, M, N, vt, vt_n0, vt_ld); \
     } else if (p8) {                                                                                                     \
       mfma256p_kernel<E, F><<<grid256, 512, 131072 + 2048, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm, tl); \
-    } else if (ring256) {                                                                                                \
-      mfma256_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);        \
     } else {                                                                                                             \
-      mfma256w_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);       \
+      mfma256_kernel<E, F><<<grid256, 512, 131072, s>>>(A, W, bias, C, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);        \
     }                                                                                                                   \
   } while (0)
     if (N % 256 == 0) {

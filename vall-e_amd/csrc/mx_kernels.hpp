@@ -357,215 +357,6 @@ __global__ __launch_bounds__(512) void mx256_kernel(const uint8_t* __restrict__ 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stages issued past the last tile
 }
 
-// ---- the same GEMM with FULL-LINE staging: a stage is 128 k (128-byte rows, two MFMA k-steps), two LDS buffers.  One
-// LDS-DMA wave-instruction then covers 8 rows x one whole 128-byte line each instead of 16 rows x half a line: half the texture /
-// L1 requests for the same bytes (cdna_hip_programming.md §5: operands "through LDS in full 128-B lines"; the 64-byte-row ring above
-// ran at ~40 GB/s per CU, the matrix cores need ~66).  Chunk swizzle for 128-byte rows: position = chunk ^ ((row >> 1) & 7).
-// Per stage and wave: 9 LDS-DMA loads (4 A, 4 W, 1 KB of scales), 24 fragment reads, 16 MFMAs, ONE barrier.
-template <int EPI, int OUT>
-__global__ __launch_bounds__(512) void mx256w_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ SA, int lda_s,
-                                                     const uint8_t* __restrict__ W, const uint8_t* __restrict__ SW, int ldw_s,
-                                                     const float* __restrict__ bias, void* __restrict__ Cv,
-                                                     uint8_t* __restrict__ SC, int ldc_s, int M, int N, int K,
-                                                     bf16* __restrict__ vt, int vt_n0, int vt_ld, int ntn, int ntiles) {
-  constexpr int STAGE = 65536 + 2048;  // A 32 KB | W 32 KB | A scales 4 x 256 | W scales 4 x 256
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int r = lane & 31, h = lane >> 5;
-  const int G = gridDim.x;
-  const int q8 = ntiles >> 3, r8 = ntiles & 7;
-  auto tile_of = [&](int v) {
-    const int xcd = v & 7, loc = v >> 3;
-    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-  };
-  const int cnt = (ntiles - (int)blockIdx.x + G - 1) / G;
-
-  // one operand stage = 2048 16-byte slots, 4 per thread: slot q = tid + 512 i -> row (tid >> 3) + 64 i, position tid & 7, which
-  // holds source chunk (tid & 7) ^ ((row >> 1) & 7) = the same chunk for all four (64 i does not reach bits 1-3 of the row)
-  const int row0 = tid >> 3;
-  const int csrc = ((tid & 7) ^ ((row0 >> 1) & 7)) * 16;
-  const int dbase = (tid - lane) * 16;  // wave-uniform LDS offset of lane 0's slot (slot i: + 8192 i)
-  const int nk = K / 128;
-  int ra[4], rw[4];                     // clamped global rows of this thread's four slots (current load tile)
-  size_t s_off = 0, s_step = 0;         // scale bytes: even waves stream the A scales, odd waves the W scales (4 k-blocks x 256)
-  const uint8_t* s_base = (wave & 1) ? SW : SA;
-  int l_ord = 0, l_k = 0, l_buf = 0;
-  auto set_load_tile = [&](int ord) {
-    const int tile = tile_of((int)blockIdx.x + min(ord, cnt - 1) * G);
-    const int mt = tile / ntn, nt = tile - mt * ntn;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = min(mt * 256 + row0 + 64 * i, M - 1);
-      rw[i] = min(nt * 256 + row0 + 64 * i, N - 1);
-    }
-    const int ld = (wave & 1) ? ldw_s : lda_s;
-    s_off = (size_t)(lane >> 4) * ld + ((wave & 1) ? nt : mt) * 256 + (lane & 15) * 16;
-    s_step = (size_t)4 * ld;
-  };
-  auto stage = [&]() {
-    unsigned char* base = lds + l_buf * STAGE;
-    const size_t k0 = (size_t)l_k * 128 + csrc;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)ra[i] * K + k0),
-                                       (__attribute__((address_space(3))) void*)(base + dbase + 8192 * i), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (size_t)rw[i] * K + k0),
-                                       (__attribute__((address_space(3))) void*)(base + 32768 + dbase + 8192 * i), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_base + s_off + (size_t)l_k * s_step),
-                                     (__attribute__((address_space(3))) void*)(base + 65536 + (wave & 1) * 1024), 16, 0, 0);
-    l_buf ^= 1;
-    if (++l_k == nk) { l_k = 0; set_load_tile(++l_ord); }
-  };
-
-  f32x16_t acc[4][2];
-  u32x4 w0[2][2], w1[2][2], aX[2][2], aY[2][2];
-  unsigned sw0 = 0, sw1 = 0, sa0 = 0, sa1 = 0;
-  auto frag = [](const u32x4 (&p)[2]) {
-    i32x8_t v;
-    v[0] = (int)p[0].x; v[1] = (int)p[0].y; v[2] = (int)p[0].z; v[3] = (int)p[0].w;
-    v[4] = (int)p[1].x; v[5] = (int)p[1].y; v[6] = (int)p[1].z; v[7] = (int)p[1].w;
-    return v;
-  };
-  // k-step ks of the stage in buffer `buf`: lane (r, h) takes chunks 4 ks + h (k-block 2 ks, bytes 16 h..) and 4 ks + 2 + h
-  // (k-block 2 ks + 1) of its rows, and supplies the scale of k-block 2 ks + h
-  auto read_w = [&](int buf, int ks, u32x4 (&w)[2][2], unsigned& sw, unsigned& sa) {
-    const unsigned char* ba = lds + buf * STAGE;
-    const unsigned char* bw = ba + 32768;
-    const unsigned char* bs = ba + 65536 + (2 * ks + h) * 256;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = wn * 64 + j * 32 + r, sz = (row >> 1) & 7;
-      w[j][0] = *reinterpret_cast<const u32x4*>(bw + row * 128 + (((4 * ks + h) ^ sz) << 4));
-      w[j][1] = *reinterpret_cast<const u32x4*>(bw + row * 128 + (((4 * ks + 2 + h) ^ sz) << 4));
-    }
-    sa = *reinterpret_cast<const unsigned*>(bs + wm * 128 + r * 4);
-    sw = *reinterpret_cast<const unsigned*>(bs + 1024 + (wn >> 1) * 128 + r * 4) >> ((wn & 1) * 16);
-  };
-  auto read_a = [&](int buf, int ks, int half, u32x4 (&a)[2][2]) {
-    const unsigned char* ba = lds + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = wm * 128 + (2 * half + i) * 32 + r, sz = (row >> 1) & 7;
-      a[i][0] = *reinterpret_cast<const u32x4*>(ba + row * 128 + (((4 * ks + h) ^ sz) << 4));
-      a[i][1] = *reinterpret_cast<const u32x4*>(ba + row * 128 + (((4 * ks + 2 + h) ^ sz) << 4));
-    }
-  };
-#define MX_MM(HALF, W, SW, A, SA)                                                                                                   \
-  do {                                                                                                                             \
-    acc[2 * HALF][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(W[0]), frag(A[0]), acc[2 * HALF][0], 0, 0, 0, (int)SW, 2 * HALF, (int)SA);         \
-    acc[2 * HALF][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(W[1]), frag(A[0]), acc[2 * HALF][1], 0, 0, 1, (int)SW, 2 * HALF, (int)SA);         \
-    acc[2 * HALF + 1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(W[0]), frag(A[1]), acc[2 * HALF + 1][0], 0, 0, 0, (int)SW, 2 * HALF + 1, (int)SA); \
-    acc[2 * HALF + 1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag(W[1]), frag(A[1]), acc[2 * HALF + 1][1], 0, 0, 1, (int)SW, 2 * HALF + 1, (int)SA); \
-  } while (0)
-
-  // Stage s lives in buffer s & 1.  On stage s: [issue stage s+1 into the other buffer] [16 MFMAs of stage s, fragments refilled a
-  // quarter-stage ahead] - before the last quarter: [this wave's loads of stage s+1 landed and its reads of stage s returned]
-  // [barrier] [first fragments of stage s+1].  After the barrier every wave's reads of buffer s & 1 are complete, so the next
-  // iteration's loads may overwrite it.
-  set_load_tile(0);
-  stage();
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  read_w(0, 0, w0, sw0, sa0);
-  read_a(0, 0, 0, aX);
-  int cur = 0;
-  for (int ord = 0; ord < cnt; ++ord) {
-    const int tile = tile_of((int)blockIdx.x + ord * G);
-    const int mt = tile / ntn, nt = tile - mt * ntn;
-    const int m0 = mt * 256, n0 = nt * 256;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-    for (int t = 0; t < nk; ++t) {
-      stage();
-      read_a(cur, 0, 1, aY);
-      MX_MM(0, w0, sw0, aX, sa0);
-      read_w(cur, 1, w1, sw1, sa1);
-      read_a(cur, 1, 0, aX);
-      MX_MM(1, w0, sw0, aY, sa0);
-      read_a(cur, 1, 1, aY);
-      MX_MM(0, w1, sw1, aX, sa1);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      cur ^= 1;
-      read_w(cur, 0, w0, sw0, sa0);
-      read_a(cur, 0, 0, aX);
-      MX_MM(1, w1, sw1, aY, sa1);
-    }
-#undef MX_MM
-
-    // epilogue: acc[i][j][v] = C[m = m0 + wm*128 + i*32 + r][n = n0 + wn*64 + j*32 + (v&3) + 8*(v>>2) + 4*h]
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int nf = n0 + wn * 64 + j * 32;  // N % 256 == 0: always in range
-      float4 bq[4];
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) bq[qd] = EPI != GE_PLAIN ? *reinterpret_cast<const float4*>(bias + nf + 8 * qd + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 128 + i * 32 + r;
-        float x[16];
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          x[4 * qd] = acc[i][j][4 * qd] + bq[qd].x; x[4 * qd + 1] = acc[i][j][4 * qd + 1] + bq[qd].y;
-          x[4 * qd + 2] = acc[i][j][4 * qd + 2] + bq[qd].z; x[4 * qd + 3] = acc[i][j][4 * qd + 3] + bq[qd].w;
-        }
-        if (EPI == GE_RELU) {
-#pragma unroll
-          for (int v = 0; v < 16; ++v) x[v] = fmaxf(x[v], 0.f);
-        }
-        if (OUT == MX_OUT_MX) {  // the row's 32 columns of this fragment are one MX block: 16 here, 16 in the other half-wave
-          float am = 0.f;
-#pragma unroll
-          for (int v = 0; v < 16; ++v) am = fmaxf(am, fabsf(x[v]));
-          am = fmaxf(am, xor32_f(am));
-          float inv;
-          const uint32_t sb = mx_block_scale(am, inv);
-          if (m < M) {
-            uint8_t* cp = reinterpret_cast<uint8_t*>(Cv) + (size_t)m * N + nf + 4 * h;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd)
-              *reinterpret_cast<uint32_t*>(cp + 8 * qd) = mx_pack4(x[4 * qd], x[4 * qd + 1], x[4 * qd + 2], x[4 * qd + 3], inv);
-            if (h == 0) SC[(size_t)(nf >> 5) * ldc_s + mx_spos(m)] = (uint8_t)sb;
-          }
-        } else if (m < M) {
-          if (OUT == MX_OUT_F32) {
-            float* cp = reinterpret_cast<float*>(Cv) + (size_t)m * N + nf + 4 * h;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-              float4* p4 = reinterpret_cast<float4*>(cp + 8 * qd);
-              if (EPI == GE_RESID) {
-                const float4 o = *p4;
-                *p4 = make_float4(o.x + x[4 * qd], o.y + x[4 * qd + 1], o.z + x[4 * qd + 2], o.w + x[4 * qd + 3]);
-              } else {
-                *p4 = make_float4(x[4 * qd], x[4 * qd + 1], x[4 * qd + 2], x[4 * qd + 3]);
-              }
-            }
-          } else {
-            bf16* cp = reinterpret_cast<bf16*>(Cv) + (size_t)m * N + nf + 4 * h;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-              union { bf16 e[4]; uint2 u; } pk;
-#pragma unroll
-              for (int v = 0; v < 4; ++v) pk.e[v] = (bf16)x[4 * qd + v];
-              *reinterpret_cast<uint2*>(cp + 8 * qd) = pk.u;
-              if (vt != nullptr && nf >= vt_n0) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) vt[(size_t)(nf + 8 * qd + 4 * h + v - vt_n0) * vt_ld + m] = pk.e[v];
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stages issued past the last tile
-}
-
 // ---- the MXFP8 256x256 GEMM on the 8-phase ping-pong schedule of mfma256p_kernel (mfma_kernels.hpp): e4m3 rows of 128 k are 128
 // bytes, exactly a bf16 row of 64 k, so the byte geometry is the same - a K-tile (128 k) is four 16 KB half-tiles (B-h0, A-h0,
 // B-h1, A-h1) in one of two 64 KB buffers, one half-tile staged per phase with four in flight, the two row groups one barrier
@@ -960,10 +751,8 @@ static inline int mx_gemm_dispatch(const uint8_t* A, const uint8_t* SA, int lda_
     return cu > 0 ? cu : 256;
   }();
   const int grid = ntn * ntm < ncu ? ntn * ntm : ncu;
-  // default: the 64-byte-row ring kernel (mx256_kernel); VX_MX_ALG=0 selects the full-line kernel (mx256w_kernel).  A/B at
-  // 117 k rows (profiles/r02_notes.md): 1335 vs 1350 TF/s - full 128-byte lines per LDS-DMA instruction buy nothing here
-  static const int alg = [] { const char* v = getenv("VX_MX_ALG"); return v ? atoi(v) : 2; }();  // 2: the 8-phase kernel (default), 1: the 32-k ring, 0: full-line staging
-  const bool p8 = alg == 2 && K % 256 == 0 && (size_t)M * K < 0xFFFF0000ull && (size_t)N * K < 0xFFFF0000ull;
+  // the 8-phase kernel needs whole pairs of 128-k tiles and 32-bit byte offsets; any other K or size runs the 32-k ring (mx256_kernel)
+  const bool p8 = K % 256 == 0 && (size_t)M * K < 0xFFFF0000ull && (size_t)N * K < 0xFFFF0000ull;
   // tail split (VX_GEMM_TAIL=1, fp32 forms only: the second launch's epilogue is the bf16 GEMM's); a K-tile here is 128 k
   const P8Tail tl = (p8 && out == MX_OUT_F32) ? p8_tail_plan(ntn * ntm, grid, K / 2, s) : P8Tail{nullptr, 0};
 #define MX(E, O)                                                                                                         \
@@ -971,7 +760,6 @@ static inline int mx_gemm_dispatch(const uint8_t* A, const uint8_t* SA, int lda_
     static bool attr_done = false;                                                                                      \
     if (!attr_done) {                                                                                                   \
       (void)hipFuncSetAttribute((const void*)mx256_kernel<E, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (32768 + 1024));  \
-      (void)hipFuncSetAttribute((const void*)mx256w_kernel<E, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (65536 + 2048)); \
       attr_done = true;                                                                                                 \
     }                                                                                                                   \
     if (p8) {                                                                                                           \
@@ -985,10 +773,8 @@ static inline int mx_gemm_dispatch(const uint8_t* A, const uint8_t* SA, int lda_
         const int nt_all = ntn * ntm, rem_t = nt_all % grid;                                                            \
         p8_tail_reduce_kernel<E, true><<<dim3(rem_t, 16), 256, 0, s>>>(tl.ws, tl.split, nt_all - rem_t, ntn, nt_all, bias, C, M, N, nullptr, 0, 0); \
       }                                                                                                                 \
-    } else if (alg != 0)                                                                                                \
+    } else                                                                                                              \
       mx256_kernel<E, O><<<grid, 512, 4 * (32768 + 1024), s>>>(A, SA, lda_s, W, SW, ldw_s, bias, C, SC, ldc_s, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm);  \
-    else                                                                                                                \
-      mx256w_kernel<E, O><<<grid, 512, 2 * (65536 + 2048), s>>>(A, SA, lda_s, W, SW, ldw_s, bias, C, SC, ldc_s, M, N, K, vt, vt_n0, vt_ld, ntn, ntn * ntm); \
   } while (0)
   if (out == MX_OUT_MX && epi == GE_RELU) MX(GE_RELU, MX_OUT_MX);
   else if (out == MX_OUT_BF16 && epi == GE_BIAS) MX(GE_BIAS, MX_OUT_BF16);
