@@ -60,7 +60,7 @@ def committed_traffic():
     """HBM traffic per batch-1 AR step from the newest committed PMC summary (profiles/r*_pmc_ar_step.json: FETCH_SIZE x2 per the
     microarch guide's gfx950 correction, a SEPARATE rocprofv3 --pmc pass, not this run).  (value at ctx, source) or (None, None)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_ar_step.json")))
-    if not files or os.environ.get("VX_AR_PREFETCH", "") == "0":
+    if not files or os.environ.get("VX_AR_TP", "") == "0":
         return None, None
     p = json.load(open(files[-1]))
     return p, os.path.relpath(files[-1], ROOT)
@@ -229,8 +229,6 @@ def run_rank(args) -> int:
     s_of = (lambda i: args.text_len - 7 + (i % 15)) if ragged else (lambda i: args.text_len)  # 40..54 around 47
     s_max = args.text_len + 7 if ragged else args.text_len
     sd = None
-    if Bt > 1:
-        os.environ.setdefault("VX_TIME_GEMMS", "1")  # HIP-event pairs around the NAR stages' GEMM launches (vx_get_timings)
     if dry:
         model, eng = _DryRunModel(), None
     else:
@@ -307,6 +305,14 @@ def run_rank(args) -> int:
     frames, outs, tms, shapes = run_phase(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
+    tms_gemm = []
+    if Bt > 1 and not dry:
+        # GEMM roofline of the batched NAR stages: ONE extra, untimed pass over the last step's utterances with a HIP-event pair
+        # around every GEMM launch (VX_TIME_GEMMS, ~500 event records per pass) - never inside the timed region
+        os.environ["VX_TIME_GEMMS"] = "1"
+        _, _, tms_gemm, _ = run_phase(args.warmup + args.steps - 1, 1)
+        os.environ.pop("VX_TIME_GEMMS")
+        fence()
     t = torch.tensor([dt, float(frames)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone()
@@ -353,8 +359,8 @@ def run_rank(args) -> int:
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(step_bytes)},
         }
-        g_ms = sum(t_.get("nar_gemm_ms", 0.0) for t_ in tms)
-        g_fl = sum(t_.get("nar_gemm_flops", 0.0) for t_ in tms)
+        g_ms = sum(t_.get("nar_gemm_ms", 0.0) for t_ in tms_gemm)
+        g_fl = sum(t_.get("nar_gemm_flops", 0.0) for t_ in tms_gemm)
         if Bt > 1 and g_ms > 0:
             fp8 = args.precision == "fp8nar"
             peak = 5000.0 if fp8 else 2500.0  # MI355X_MICROARCH.md: dense fp8 / bf16 MFMA peak, TFLOP/s
@@ -362,8 +368,9 @@ def run_rank(args) -> int:
             gemm = {"bound": "mfma", "kernel": ("NAR stage GEMMs on MXFP8 (QKV, FFN1, FFN2: mx256p_kernel)" if fp8 else
                                                   "NAR stage GEMMs in bf16 (QKV, out-projection, FFN1, FFN2: mfma256p_kernel)"),
                     "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
-                    "flops_per_launch": int(g_fl / max(1, len(tms))), "ms_per_launch": round(g_ms / max(1, len(tms)), 3),
-                    "note": "algorithmic 2 M N K of every timed GEMM / HIP-event time around the launches on the engine stream"}
+                    "flops_per_launch": int(g_fl / max(1, len(tms_gemm))), "ms_per_launch": round(g_ms / max(1, len(tms_gemm)), 3),
+                    "note": "algorithmic 2 M N K of every GEMM of one NAR pass / HIP-event time around its launches on the engine stream, "
+                            "collected in ONE extra pass after the timed region (the timed steps carry no extra events)"}
             if fp8:  # configs[4]: the fp8 GEMMs are the kernel this configuration is about; the AR step's line moves aside
                 out["ar_step_roofline"], out["roofline"] = out["roofline"], gemm
             else:
@@ -372,7 +379,11 @@ def run_rank(args) -> int:
             prof, src = committed_traffic()
             if prof is not None:
                 ctx_mean = args.text_len + P_PROMPT + (T_show - 1) / 2.0
-                out["roofline"]["traffic"] = int(prof["gemv_bytes_per_step_corrected"] + prof["attn_bytes_per_ctx_row_corrected"] * ctx_mean)
+                if "gemv_bytes_per_step_corrected" in prof:  # round 1-2 summaries: GEMV and attention launches apart
+                    out["roofline"]["traffic"] = int(prof["gemv_bytes_per_step_corrected"] + prof["attn_bytes_per_ctx_row_corrected"] * ctx_mean)
+                else:  # the sharded step reads its K / V rows inside the attention launch: measured bytes at the collection's
+                    # mean context, moved to this run's by the algorithmic 49 152 B per cached row
+                    out["roofline"]["traffic"] = int(prof["hbm_bytes_per_step_corrected"] + 49152 * (ctx_mean - prof["ctx_mean"]))
                 out["roofline"]["traffic_source"] = (f"{src}: FETCH_SIZE x2 from a separate rocprofv3 --pmc pass of an eager (no-graph) run, "
                                                      "quoted at this run's mean context; NOT measured in this run")
                 if prof.get("write_bytes_per_step"):

@@ -43,6 +43,24 @@ constexpr int VX_KSTAMP_EXTRA = 0;
 
 namespace vx {
 
+// Host: per-DEVICE caches for launch helpers (an engine may live on any device of the process: a process-wide `static bool
+// done` would set a kernel's max-dynamic-LDS attribute on the first device only and reuse its CU count everywhere).
+inline int vx_cur_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return (d < 0 || d >= 16) ? 0 : d;
+}
+inline int vx_cu_count() {
+  static int cu[16] = {};
+  const int d = vx_cur_device();
+  if (cu[d] <= 0) {
+    int n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d);
+    cu[d] = n > 0 ? n : 256;
+  }
+  return cu[d];
+}
+
 constexpr int WAVE = 64;
 constexpr int NUM_AUDIO_TOKENS = 1024;  // valle/models/macros.py:5
 constexpr int AR_VOCAB = 1025;          // ar_predict_layer rows (valle.py:153-155)

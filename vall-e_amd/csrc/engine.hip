@@ -974,7 +974,8 @@ static int split_for(int K) {  // K slices of the split-K GEMMs: a multiple of t
 
 static bool use_mfma(const vx_engine* e);
 static bool time_gemms() {
-  static const bool on = [] { const char* v = getenv("VX_TIME_GEMMS"); return v && atoi(v) != 0; }();
+  const char* v = getenv("VX_TIME_GEMMS");  // read per call: bench.py turns it on for ONE extra, untimed pass
+  const bool on = v && atoi(v) != 0;
   return on;
 }
 // event before / after a GEMM launch on the engine stream (no-op unless VX_TIME_GEMMS=1)
@@ -2443,28 +2444,35 @@ extern "C" int vx_op_gemm_rows(int32_t form, const void* A, const void* Wp, cons
 extern "C" int vx_op_gemm_mx(const float* A, const float* Wt, const float* bias, void* c_out, void* sc_out, int32_t M, int32_t N,
                              int32_t K, int32_t relu, int32_t out_mode, void* qa_out, void* sa_out, void* stream) {
   if (!A || !Wt || !c_out || M < 1 || N % 256 || K % 128) return fail(VX_ERR_UNSUPPORTED, "mx gemm: M=%d N=%d K=%d (N %% 256, K %% 128)", M, N, K);
+  if (out_mode == 2 && !sc_out) return fail(VX_ERR_ARG, "mx gemm: out_mode 2 needs sc_out");  // arguments first, allocations after
   hipStream_t s = (hipStream_t)stream;
   const int ld = (M + 255) / 256 * 256;
-  uint8_t *qa = nullptr, *sa = nullptr, *qw = nullptr, *sw = nullptr;
-  HIPC(hipMalloc((void**)&qa, (size_t)M * K)); HIPC(hipMalloc((void**)&sa, (size_t)(K / 32) * ld));
-  HIPC(hipMalloc((void**)&qw, (size_t)N * K)); HIPC(hipMalloc((void**)&sw, (size_t)(K / 32) * N));
-  HIPC(hipMemsetAsync(sa, 0, (size_t)(K / 32) * ld, s));
-  mx_quant_rows_kernel<<<(M + 3) / 4, 256, 0, s>>>(A, qa, sa, M, K, ld);
-  mx_quant_rows_kernel<<<(N + 3) / 4, 256, 0, s>>>(Wt, qw, sw, N, K, N);
+  struct Scratch {  // freed on every exit path
+    uint8_t *qa = nullptr, *sa = nullptr, *qw = nullptr, *sw = nullptr;
+    ~Scratch() { (void)hipFree(qa); (void)hipFree(sa); (void)hipFree(qw); (void)hipFree(sw); }
+  } t;
+  HIPC(hipMalloc((void**)&t.qa, (size_t)M * K)); HIPC(hipMalloc((void**)&t.sa, (size_t)(K / 32) * ld));
+  HIPC(hipMalloc((void**)&t.qw, (size_t)N * K)); HIPC(hipMalloc((void**)&t.sw, (size_t)(K / 32) * N));
+  HIPC(hipMemsetAsync(t.sa, 0, (size_t)(K / 32) * ld, s));
+  mx_quant_rows_kernel<<<(M + 3) / 4, 256, 0, s>>>(A, t.qa, t.sa, M, K, ld);
+  mx_quant_rows_kernel<<<(N + 3) / 4, 256, 0, s>>>(Wt, t.qw, t.sw, N, K, N);
+  HIPC(hipGetLastError());  // a quantiser launch failure is reported as such, not as the GEMM's
   int rc;
   if (out_mode == 2) {
-    if (!sc_out) return fail(VX_ERR_ARG, "mx gemm: out_mode 2 needs sc_out");
     HIPC(hipMemsetAsync(sc_out, 0, (size_t)(N / 32) * ld, s));
-    rc = mx_gemm_dispatch(qa, sa, ld, qw, sw, N, bias, c_out, (uint8_t*)sc_out, ld, M, N, K, GE_RELU, MX_OUT_MX, s);
+    rc = mx_gemm_dispatch(t.qa, t.sa, ld, t.qw, t.sw, N, bias, c_out, (uint8_t*)sc_out, ld, M, N, K, GE_RELU, MX_OUT_MX, s);
   } else {
-    rc = mx_gemm_dispatch(qa, sa, ld, qw, sw, N, bias, c_out, nullptr, 0, M, N, K, relu ? GE_RELU : (bias ? GE_BIAS : GE_PLAIN), MX_OUT_F32, s);
+    rc = mx_gemm_dispatch(t.qa, t.sa, ld, t.qw, t.sw, N, bias, c_out, nullptr, 0, M, N, K, relu ? GE_RELU : (bias ? GE_BIAS : GE_PLAIN), MX_OUT_F32, s);
   }
+  hipError_t le = hipGetLastError();
+  if (rc == 0 && le == hipSuccess) {
+    if (qa_out) le = hipMemcpyAsync(qa_out, t.qa, (size_t)M * K, hipMemcpyDefault, s);
+    if (le == hipSuccess && sa_out) le = hipMemcpyAsync(sa_out, t.sa, (size_t)(K / 32) * ld, hipMemcpyDefault, s);
+  }
+  const hipError_t se = hipStreamSynchronize(s);  // the scratch is in use until the stream has drained, whatever happened
   if (rc) return fail(VX_ERR_UNSUPPORTED, "mx gemm: no kernel instance (rc %d)", rc);
-  HIPC(hipGetLastError());
-  if (qa_out) HIPC(hipMemcpyAsync(qa_out, qa, (size_t)M * K, hipMemcpyDefault, s));
-  if (sa_out) HIPC(hipMemcpyAsync(sa_out, sa, (size_t)(K / 32) * ld, hipMemcpyDefault, s));
-  HIPC(hipStreamSynchronize(s));
-  (void)hipFree(qa); (void)hipFree(sa); (void)hipFree(qw); (void)hipFree(sw);
+  HIPC(le);
+  HIPC(se);
   return VX_OK;
 }
 

@@ -1092,12 +1092,7 @@ __global__ __launch_bounds__(512) void mfma256p_kernel(const bf16* __restrict__ 
 static inline int gemm_ring128(long long wgs) {
   static const int forced = [] { const char* v = getenv("VX_GEMM_RING"); return (v && *v >= '0' && *v <= '9') ? atoi(v) : -1; }();
   if (forced == 0 || forced == 32 || forced == 64) return forced;
-  static const int ncu = [] {
-    int dev = 0, cu = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
-    return cu > 0 ? cu : 256;
-  }();
+  const int ncu = vx_cu_count();
   return wgs <= ncu ? 64 : 32;
 }
 
@@ -1155,12 +1150,7 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
   const long long tiles64 = (long long)((M + 63) / 64) * (N / 64);
   if ((alg == 3 || (alg == 0 && M >= 4096)) && N % 256 == 0 && K >= 128) {  // K % 64 == 0 checked above  // enough 256^2 tiles for several per CU
     const int ntn = N / 256, ntm = (M + 255) / 256;
-    static const int ncu = [] {
-      int dev = 0, cu = 256;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
-      return cu > 0 ? cu : 256;
-    }();
+    const int ncu = vx_cu_count();
     const int grid256 = ntn * ntm < ncu ? ntn * ntm : ncu;  // one persistent workgroup per CU (128 KB of LDS each)
     // the 8-phase schedule needs whole pairs of 64-k tiles and 32-bit byte offsets into A and W; any other K or size runs the
     // 32-k ring (mfma256_kernel)
@@ -1168,7 +1158,7 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
     const P8Tail tl = p8 ? p8_tail_plan(ntn * ntm, grid256, K, s) : P8Tail{nullptr, 0};  // all forms; in this model only the K = 4096 one (FFN2) ever splits
 #define M2(E, F)                                                                                                         \
   do {                                                                                                                  \
-    static bool attr_done = false;                                                                                      \
+    static bool attr_dev[16] = {}; bool& attr_done = attr_dev[vx_cur_device()];                                                                                      \
     if (!attr_done) {                                                                                                   \
       (void)hipFuncSetAttribute((const void*)mfma256_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);  \
       (void)hipFuncSetAttribute((const void*)mfma256p_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 2048); \
@@ -1200,7 +1190,7 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
     dim3 grid((N + 127) / 128, (M + 127) / 128);
 #define MG(E, F)                                                                                                        \
   do {                                                                                                                  \
-    static bool attr_done = false;                                                                                      \
+    static bool attr_dev[16] = {}; bool& attr_done = attr_dev[vx_cur_device()];                                                                                      \
     if (!attr_done) {                                                                                                   \
       (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<E, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
       (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<E, F, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
@@ -1225,7 +1215,7 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
   const size_t lds = 131072;
 #define WG(E, F, S)                                                                                                     \
   do {                                                                                                                  \
-    static bool attr_done = false;                                                                                      \
+    static bool attr_dev[16] = {}; bool& attr_done = attr_dev[vx_cur_device()];                                                                                      \
     if (!attr_done) {                                                                                                   \
       (void)hipFuncSetAttribute((const void*)wgemm_kernel<E, F, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       attr_done = true;                                                                                                 \
@@ -1258,7 +1248,7 @@ static inline int mfma_gemm_dispatch(const bf16* A, const bf16* W, const float* 
 // C_z = A[:, zK/s:(z+1)K/s] . W[:, same]^T for z < splits, each into its own fp32 (M, N) slab: the N = d GEMMs
 // (out-projection, FFN2) at M ~ 1k rows, where 128^2 tiles alone give 72 workgroups.  splits in {1,2,4}.
 static inline int mfma_gemm_partial(const bf16* A, const bf16* W, float* slabs, int M, int N, int K, int splits, hipStream_t s) {
-  static bool attr_done = false;
+  static bool attr_dev[16] = {}; bool& attr_done = attr_dev[vx_cur_device()];
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<GE_PLAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)mfma_gemm_kernel<GE_PLAIN, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -1542,7 +1532,7 @@ static inline int mfma_attn_dispatch(const bf16* qkv, const bf16* vt, int vt_ld,
   dim3 grid((rows + 32 * NW - 1) / (32 * NW), H, seg_start ? nseg : 1);
   // fewer than ~2 workgroups per CU: split the keys over two wave groups inside the workgroup (4 waves = all 4 SIMDs)
   static const int kgsel = [] { const char* v = getenv("VX_ATTN_KG"); return v ? atoi(v) : 0; }();  // A/B runs
-  static bool attr_done = false;
+  static bool attr_dev[16] = {}; bool& attr_done = attr_dev[vx_cur_device()];
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)mfma_attn_kernel<NW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)mfma_attn_kernel<NW, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);

@@ -744,12 +744,7 @@ static inline int mx_gemm_dispatch(const uint8_t* A, const uint8_t* SA, int lda_
                                    hipStream_t s, bf16* vt = nullptr, int vt_n0 = 0, int vt_ld = 0) {
   if (N % 256 != 0 || K % 128 != 0 || M < 1) return 1;
   const int ntn = N / 256, ntm = (M + 255) / 256;
-  static const int ncu = [] {
-    int dev = 0, cu = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
-    return cu > 0 ? cu : 256;
-  }();
+  const int ncu = vx_cu_count();
   const int grid = ntn * ntm < ncu ? ntn * ntm : ncu;
   // the 8-phase kernel needs whole pairs of 128-k tiles and 32-bit byte offsets; any other K or size runs the 32-k ring (mx256_kernel)
   const bool p8 = K % 256 == 0 && (size_t)M * K < 0xFFFF0000ull && (size_t)N * K < 0xFFFF0000ull;
@@ -757,13 +752,13 @@ static inline int mx_gemm_dispatch(const uint8_t* A, const uint8_t* SA, int lda_
   const P8Tail tl = (p8 && out == MX_OUT_F32) ? p8_tail_plan(ntn * ntm, grid, K / 2, s) : P8Tail{nullptr, 0};
 #define MX(E, O)                                                                                                         \
   do {                                                                                                                  \
-    static bool attr_done = false;                                                                                      \
+    static bool attr_dev[16] = {}; bool& attr_done = attr_dev[vx_cur_device()];                                                                                      \
     if (!attr_done) {                                                                                                   \
       (void)hipFuncSetAttribute((const void*)mx256_kernel<E, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (32768 + 1024));  \
       attr_done = true;                                                                                                 \
     }                                                                                                                   \
     if (p8) {                                                                                                           \
-      static bool attr_p = false;                                                                                       \
+      static bool attr_pdev[16] = {}; bool& attr_p = attr_pdev[vx_cur_device()];                                                                                       \
       if (!attr_p) {                                                                                                    \
         (void)hipFuncSetAttribute((const void*)mx256p_kernel<E, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (65536 + 2048) + 2048); \
         attr_p = true;                                                                                                  \

@@ -20,6 +20,16 @@ from .weights import expected_keys, synthetic_state_dict, tied_keys
 _IncompatibleKeys = namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
 
 
+def _ids_out_of_range(x: torch.Tensor, y: torch.Tensor) -> bool:
+    """Text ids outside [0, NUM_TEXT_TOKENS) or codec ids outside [0, NUM_AUDIO_TOKENS): both tests on the device, ONE
+    device-to-host read (four `int(t.min())`-style syncs before).  An empty prompt is legal with prepend_bos."""
+    tx, ty = x.reshape(-1), y.reshape(-1)
+    flags = [((tx < 0) | (tx >= NUM_TEXT_TOKENS)).any()]
+    if ty.numel():
+        flags.append(((ty < 0) | (ty >= NUM_AUDIO_TOKENS)).any())
+    return bool(torch.stack(flags).any())
+
+
 class VALLE:
     """Decoder-only VALL-E (inference only).  Engine-specific keyword arguments (not in the
     reference): ``precision`` ("bf16" | "fp32"), ``max_text``, ``max_audio`` (capacities),
@@ -138,8 +148,7 @@ class VALLE:
             raise RuntimeError(f"x must be one unpadded sequence: x {tuple(x.shape)} vs x_lens.max() {S}")
         eng = self.engine()
         Q, bos = self.num_quantizers, int(self.ar_audio_prepend_bos)
-        if int(x.min()) < 0 or int(x.max()) >= NUM_TEXT_TOKENS or (y.shape[1] > 0 and (  # an empty prompt is legal with prepend_bos
-                int(y.min()) < 0 or int(y[..., :Q].max()) >= NUM_AUDIO_TOKENS)):
+        if _ids_out_of_range(x, y[..., :Q]):
             raise IndexError("index out of range in self")  # what nn.Embedding raises in the reference
         text = x[0]
         prompts = y[0, :, :Q].contiguous()
@@ -198,8 +207,7 @@ class VALLE:
                 assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3 and y.shape[0] == 1 and torch.all(x_lens > 0)
                 if x.shape[1] != int(x_lens.max()) or x.shape[0] != 1:
                     raise RuntimeError("x must be one unpadded sequence per utterance")
-                if int(x.min()) < 0 or int(x.max()) >= NUM_TEXT_TOKENS or (y.shape[1] > 0 and (  # an empty prompt is legal with prepend_bos
-                int(y.min()) < 0 or int(y[..., :Q].max()) >= NUM_AUDIO_TOKENS)):
+                if _ids_out_of_range(x, y[..., :Q]):
                     raise IndexError("index out of range in self")
                 if not (batched_prefill and eng.mfma_rows):
                     eng.batch_prefill(b, x[0], y[0, :, 0].contiguous())
@@ -244,7 +252,7 @@ class VALLE:
         assert y.shape[0] == 1, y.shape
         assert torch.all(x_lens > 0)
         assert self.num_quantizers == 8
-        if int(x.min()) < 0 or int(x.max()) >= NUM_TEXT_TOKENS or int(y.min()) < 0 or int(y.max()) >= NUM_AUDIO_TOKENS:
+        if _ids_out_of_range(x, y):
             raise IndexError("index out of range in self")
         eng = self.engine()
         prefix_len = min(int(y.shape[1] * 0.5), 3 * 75)
