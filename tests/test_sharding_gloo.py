@@ -118,3 +118,35 @@ def test_bench_launcher_spawns_ranks_on_gloo():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
+
+
+def test_bench_batch32_two_ranks_returns_codes_in_utterance_order(tmp_path):
+    """BASELINE configs[3]'s code path at world size 2 on gloo: `bench.py --gpus 2 --batch 32` (ragged S in [40, 54]) with the
+    stand-in decoder - plan_partition (sort by S, contiguous groups of 32, snake deal) -> scatter -> inference_batch per rank ->
+    gather.  Rank 0 must end up with every utterance's codes at the utterance's own index: length 16 S + 1 and the stand-in's
+    checksum of THAT utterance's inputs (a permutation error of the plan / scatter / gather would move them)."""
+    import json
+    import subprocess
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from valle_amd.weights import synthetic_inputs
+
+    dump = tmp_path / "codes.json"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["VX_BENCH_DUMP"] = str(dump)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "32",
+                        "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    got = json.load(open(dump))
+    assert rec["n_gpus"] == 2 and len(got) == 64
+    model = bench._DryRunModel()
+    total = 0
+    for i, (T, chk) in enumerate(got):
+        S = bench.S_TEXT - 7 + (i % 15)
+        x, xl, y = synthetic_inputs(S, bench.P_PROMPT, 8, seed=1 + i)
+        want = model.inference(x, xl, y, None)
+        assert T == 16 * S + 1 == want.shape[1] and chk == int(want.sum()), i
+        total += T
+    assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 - total) < 0.01 * total
