@@ -86,7 +86,7 @@ def test_fp32_engine_full_length(name, T):
 def test_sharded_step_matches_plain_step_beyond_one_key_pass(monkeypatch):
     """The XCD-sharded decode step (ar_tp.hpp) keeps 16 x 128 cached keys per head in registers; a longer context takes further
     passes with plain loads.  d=1024 / 16 heads / 2 layers in fp32, S=60, P=900, 1300 forced tokens: context 961 -> 2260 rows.
-    The sharded step and the plain five-launch step (VX_AR_TP=0 VX_AR_FUSED=0, itself pinned by every fixture) must give the
+    The sharded step and the plain five-launch step (VX_AR_TP=0, itself pinned by every fixture) must give the
     same logits at every traced pass up to summation order, and the same argmax wherever the margin exceeds that."""
     from valle_amd.config import ModelConfig
     from valle_amd.models import VALLE
@@ -102,7 +102,6 @@ def test_sharded_step_matches_plain_step_beyond_one_key_pass(monkeypatch):
     rows = []
     for tp in ("1", "0"):
         monkeypatch.setenv("VX_AR_TP", tp)
-        monkeypatch.setenv("VX_AR_FUSED", tp)
         m = VALLE(1024, 16, 2, prefix_mode=1, precision="fp32", max_text=64, max_audio=2304, print_eos=False, trace_logits=True)
         m.load_state_dict(sd)
         m.to("cuda:0").eval()

@@ -3,7 +3,7 @@
 // What a launch boundary costs on this part (1.65 us floor + a fabric round trip for the vector the previous launch wrote,
 // 3.2-4.5 us per dependent launch in situ, profiles/r02_notes.md) is what an exchange between workgroups on DIFFERENT XCDs
 // costs whichever way it is done - but an exchange among the 32 workgroups of ONE XCD goes through that XCD's L2 and costs
-// 0.35-0.6 us (measured in situ with ar_fused.hpp, profiles/r03_notes.md).  So the layer is cut like a tensor-parallel
+// 0.35-0.6 us (measured in situ, profiles/r03_notes.md).  So the layer is cut like a tensor-parallel
 // transformer over 8 devices, an XCD playing the device (d = 1024, 16 heads; workgroup b: XCD x = b % 8, local index i = b / 8):
 //
 //   tp_attn_kernel  XCD x owns heads 2x, 2x+1.   LN1 of the full row (every workgroup, cooperatively), the 12 q / k / v rows
@@ -17,13 +17,13 @@
 //   tp_head_kernel  final norm of (x + bias + partials) and the 1025 logit rows.
 //
 // The cross-XCD sums travel over the launch boundary (the consumer adds the 8 partials in a fixed order: deterministic, no
-// atomics); everything inside a launch is tagged granules (ar_fused.hpp).  All weights of a launch are requested at its start,
+// atomics); everything inside a launch is tagged granules (ar_granules.hpp).  All weights of a launch are requested at its start,
 // so the in-launch stages pay a hop and their arithmetic, not a memory latency.  Placement (blockIdx % 8 == XCD) is a speed
 // assumption only: the granules are written through (sc1) and polled with sc1 loads, valid across XCDs.
 // Reference arithmetic: valle/modules/transformer.py:297-334 (pre-norm encoder layer), activation.py:407-427.
 #pragma once
 #include <type_traits>
-#include "ar_fused.hpp"
+#include "ar_granules.hpp"
 
 namespace vx {
 

@@ -20,7 +20,6 @@ __device__ unsigned long long* g_vx_kstamps = nullptr;
 __device__ unsigned long long* g_fq_stamps = nullptr;
 #endif
 #include "ar_kernels.hpp"
-#include "ar_fused.hpp"
 #include "ar_tp.hpp"
 #include "rows_kernels.hpp"
 #include "mfma_kernels.hpp"
@@ -121,9 +120,8 @@ struct vx_engine {
   int ctx_max = 0;
   float *ar_x = nullptr, *ar_xn = nullptr, *ar_q = nullptr, *ar_part = nullptr, *ar_f = nullptr, *ar_logits = nullptr;
   void* kv = nullptr;  // [L][2][H][ctx_max][hd]
-  // fused QKV + attention launch of the decode step (ar_fused.hpp): per-layer granule scratch, its output vector, the step
-  // counter that tags the granules ([0]) and the spin-timeout word ([1])
-  bool fused = false;
+  // in-launch hand-overs of the sharded decode step (ar_granules.hpp): per-layer granule scratch, the step counter that tags the
+  // granules ([0]) and the spin-timeout word ([1])
   // XCD-sharded decode step (ar_tp.hpp): two launches per layer.  Re-laid-out out-projection / linear2 weights per layer, the
   // partial-sum vectors of the two sharded GEMVs, the second residual buffer, the hidden-unit granules
   bool tp = false;
@@ -132,7 +130,6 @@ struct vx_engine {
   float* tp_gbb = nullptr;  // (2 L + 1, 3, d): {gamma, beta, arriving bias} per norm site of the step
   fq_gran* tp_gh = nullptr;
   fq_gran *fq_gq = nullptr, *fq_gp = nullptr;
-  float* ar_attn = nullptr;
   unsigned* d_epoch = nullptr;
   ArState* d_st = nullptr;
   ArState* h_st = nullptr;  // pinned: [0] staging, [1..2] poll slots
@@ -332,7 +329,7 @@ static void host_sine_table(std::vector<float>& t, int rows, int d) {
 
 // ------------------------------------------------------------------------------ create/destroy
 static int create_body(vx_engine* e);
-static int fused_setup(vx_engine* e);
+static int tp_setup(vx_engine* e);
 extern "C" void vx_destroy(vx_engine* e);
 extern "C" int vx_create(const vx_config* cfg, vx_engine** out) {
   if (!cfg || !out) return fail(VX_ERR_ARG, "null argument");
@@ -420,7 +417,7 @@ static int create_body(vx_engine* e) {
     const unsigned init[2] = {1u, 0u};  // tags start at 1: zero-filled granules never match
     HIPC(hipMemcpy(e->d_epoch, init, sizeof init, hipMemcpyHostToDevice));
   }
-  VXC(fused_setup(e));
+  VXC(tp_setup(e));
   const size_t nlog = (c.flags & VX_FLAG_TRACE_LOGITS) ? (size_t)c.max_audio + 2 : 1;
   VXC(dalloc_t(e, &e->ar_logits, LOGITS_CUR + nlog * AR_VOCAB));
   VXC(dalloc(e, &e->kv, (size_t)c.num_layers * 2 * H * e->ctx_max * hd * e->esz));
@@ -783,95 +780,46 @@ static int launch_gemv(bool bf, const GemvArgs& a, int num_cu, hipStream_t s) {
   return bf ? launch_gemv_t<bf16>(a, num_cu, s) : launch_gemv_t<float>(a, num_cu, s);
 }
 
-// ---- fused QKV + attention launch of the batch-1 decode step (ar_fused.hpp) ----
-template <typename WT, int PRO> static const void* fused_fn(int kch) {
-  switch (kch) {
-    case 1: return (const void*)qkv_attn_kernel<WT, 1, PRO>;
-    case 2: return (const void*)qkv_attn_kernel<WT, 2, PRO>;
-    case 4: return (const void*)qkv_attn_kernel<WT, 4, PRO>;
-  }
-  return nullptr;
-}
-static int fused_kch(const vx_engine* e) {
-  const int vec = e->bf16 ? 8 : 4, need = (e->cfg.d_model + 64 * vec - 1) / (64 * vec);
-  int kch = 1;
-  while (kch < need) kch <<= 1;
-  return kch;
-}
-// Chosen when the geometry fits (head_dim 64, the row in <= 4 chunks per lane) AND all 16 nhead workgroups of the launch are
-// resident at once - its hand-overs spin.  VX_AR_FUSED=0 keeps the three-launch form (A/B runs, probe builds).
-static int fused_setup(vx_engine* e) {
+// ---- the XCD-sharded decode step (ar_tp.hpp): chosen at vx_create when the geometry is BASELINE's (d = 1024, 16 heads, pre-norm,
+// no prenets, VALL-E) AND all 256 workgroups of its launches are resident at once - their hand-overs spin.  VX_AR_TP=0 keeps the
+// five-launch step (A/B runs, probe builds).
+static int tp_setup(vx_engine* e) {
   const vx_config& c = e->cfg;
   const int d = c.d_model, H = c.nhead;
-  e->fused = false;
-  const char* env = getenv("VX_AR_FUSED");
-  if (env && atoi(env) == 0) return VX_OK;
-  if (e->vallf || H <= 0 || d != 64 * H || d % (e->bf16 ? 8 : 4) || fused_kch(e) > 4) return VX_OK;
-  int per_cu = 0;
-  for (int pro : {PRO_LN, PRO_COPY}) {
-    const void* fn = e->bf16 ? (pro == PRO_LN ? fused_fn<bf16, PRO_LN>(fused_kch(e)) : fused_fn<bf16, PRO_COPY>(fused_kch(e)))
-                             : (pro == PRO_LN ? fused_fn<float, PRO_LN>(fused_kch(e)) : fused_fn<float, PRO_COPY>(fused_kch(e)));
-    int n = 0;
-    HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, 0));
-    per_cu = (pro == PRO_LN || n < per_cu) ? n : per_cu;
+  e->tp = false;
+  const char* tv = getenv("VX_AR_TP");
+  if ((tv && atoi(tv) == 0) || e->vallf || d != TP_D || H != TP_H || (c.flags & (VX_FLAG_POST_NORM | VX_FLAG_PRENET))) return VX_OK;
+  int n1 = 0, n2 = 0;
+  if (e->bf16) {
+    HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, (const void*)tp_attn_kernel<bf16, true>, 256, 0));
+    HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, (const void*)tp_ffn_kernel<bf16>, 256, 0));
+  } else {
+    HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, (const void*)tp_attn_kernel<float, true>, 256, 0));
+    HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, (const void*)tp_ffn_kernel<float>, 256, 0));
   }
-  if ((long long)per_cu * e->num_cu < (long long)FQ_G * H) return VX_OK;
+  if ((long long)(n1 < n2 ? n1 : n2) * e->num_cu < TP_X * TP_WG) return VX_OK;
   const size_t L = (size_t)c.num_layers;
-  // the XCD-sharded step: BASELINE geometry only (d = 1024, 16 heads), pre-norm, no prenets; VX_AR_TP=0 turns it off
-  {
-    const char* tv = getenv("VX_AR_TP");
-    int n1 = 0, n2 = 0;
-    if (e->bf16) {
-      HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, (const void*)tp_attn_kernel<bf16, true>, 256, 0));
-      HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, (const void*)tp_ffn_kernel<bf16>, 256, 0));
-    } else {
-      HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, (const void*)tp_attn_kernel<float, true>, 256, 0));
-      HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, (const void*)tp_ffn_kernel<float>, 256, 0));
-    }
-    e->tp = !(tv && atoi(tv) == 0) && d == TP_D && H == TP_H && !(c.flags & (VX_FLAG_POST_NORM | VX_FLAG_PRENET)) &&
-            (long long)(n1 < n2 ? n1 : n2) * e->num_cu >= TP_X * TP_WG;
-    if (e->tp) {
-      VXC(dalloc_t(e, &e->tp_part_o, (size_t)TP_X * TP_D));
-      VXC(dalloc_t(e, &e->tp_part_f, (size_t)TP_X * TP_D));
-      VXC(dalloc_t(e, &e->tp_x1, (size_t)TP_D));
-      VXC(dalloc_t(e, &e->tp_gh, L * TP_X * TP_HID));
-      VXC(dalloc_t(e, &e->tp_gbb, (2 * L + 1) * 3 * TP_D));
-      HIPC(hipMemset(e->tp_gbb, 0, (2 * L + 1) * 3 * TP_D * 4));
-      HIPC(hipMemset(e->tp_part_o, 0, (size_t)TP_X * TP_D * 4));
-      HIPC(hipMemset(e->tp_part_f, 0, (size_t)TP_X * TP_D * 4));
-      HIPC(hipMemset(e->tp_x1, 0, (size_t)TP_D * 4));
-      HIPC(hipMemset(e->tp_gh, 0, L * TP_X * TP_HID * sizeof(fq_gran)));
-      e->tp_wo.assign(L, nullptr); e->tp_w2.assign(L, nullptr);
-      for (size_t li = 0; li < L; ++li) {
-        VXC(dalloc(e, &e->tp_wo[li], (size_t)TP_D * TP_D * e->esz));
-        VXC(dalloc(e, &e->tp_w2[li], (size_t)TP_D * TP_FF * e->esz));
-      }
-    }
-  }
+  VXC(dalloc_t(e, &e->tp_part_o, (size_t)TP_X * TP_D));
+  VXC(dalloc_t(e, &e->tp_part_f, (size_t)TP_X * TP_D));
+  VXC(dalloc_t(e, &e->tp_x1, (size_t)TP_D));
+  VXC(dalloc_t(e, &e->tp_gh, L * TP_X * TP_HID));
+  VXC(dalloc_t(e, &e->tp_gbb, (2 * L + 1) * 3 * TP_D));
   VXC(dalloc_t(e, &e->fq_gq, L * H * FQ_QKV));
   VXC(dalloc_t(e, &e->fq_gp, L * H * FQ_G * FQ_PART));
-  VXC(dalloc_t(e, &e->ar_attn, d));
+  HIPC(hipMemset(e->tp_gbb, 0, (2 * L + 1) * 3 * TP_D * 4));
+  HIPC(hipMemset(e->tp_part_o, 0, (size_t)TP_X * TP_D * 4));
+  HIPC(hipMemset(e->tp_part_f, 0, (size_t)TP_X * TP_D * 4));
+  HIPC(hipMemset(e->tp_x1, 0, (size_t)TP_D * 4));
+  HIPC(hipMemset(e->tp_gh, 0, L * TP_X * TP_HID * sizeof(fq_gran)));  // zero tags: never equal to a step counter (starts at 1)
   HIPC(hipMemset(e->fq_gq, 0, L * H * FQ_QKV * sizeof(fq_gran)));
   HIPC(hipMemset(e->fq_gp, 0, L * H * FQ_G * FQ_PART * sizeof(fq_gran)));
-  HIPC(hipMemset(e->ar_attn, 0, d * sizeof(float)));
-  e->fused = true;
-  return VX_OK;
-}
-template <typename WT, int PRO> static int launch_fused_p(const vx_engine* e, const void* Wm, const float* x, const float* g, const float* b,
-                                                          const FusedArgs& a, hipStream_t s) {
-  const int grid = FQ_G * a.nhead;
-  switch (fused_kch(e)) {
-    case 1: qkv_attn_kernel<WT, 1, PRO><<<grid, 256, 0, s>>>(Wm, x, g, b, (unsigned)a.d, a); break;
-    case 2: qkv_attn_kernel<WT, 2, PRO><<<grid, 256, 0, s>>>(Wm, x, g, b, (unsigned)a.d, a); break;
-    case 4: qkv_attn_kernel<WT, 4, PRO><<<grid, 256, 0, s>>>(Wm, x, g, b, (unsigned)a.d, a); break;
-    default: return fail(VX_ERR_UNSUPPORTED, "fused decode launch: d_model %d", a.d);
+  e->tp_wo.assign(L, nullptr); e->tp_w2.assign(L, nullptr);
+  for (size_t li = 0; li < L; ++li) {
+    VXC(dalloc(e, &e->tp_wo[li], (size_t)TP_D * TP_D * e->esz));
+    VXC(dalloc(e, &e->tp_w2[li], (size_t)TP_D * TP_FF * e->esz));
   }
+  e->tp = true;
   return VX_OK;
-}
-static int launch_fused(const vx_engine* e, int pro, const void* Wm, const float* x, const float* g, const float* b, const FusedArgs& a,
-                        hipStream_t s) {
-  if (e->bf16) return pro == PRO_LN ? launch_fused_p<bf16, PRO_LN>(e, Wm, x, g, b, a, s) : launch_fused_p<bf16, PRO_COPY>(e, Wm, x, g, b, a, s);
-  return pro == PRO_LN ? launch_fused_p<float, PRO_LN>(e, Wm, x, g, b, a, s) : launch_fused_p<float, PRO_COPY>(e, Wm, x, g, b, a, s);
 }
 
 template <typename T>
@@ -1512,22 +1460,6 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     }
     warm(a, 4 * li);
     a.nt = ar_nt; a.kid = 1 + 5 * li;
-    if (e->fused) {  // QKV + attention + combine in one launch; the out-projection reads the finished 4 KB vector
-      FusedArgs fa{};
-      fa.bias = l.in_b; fa.st = e->d_st; fa.epoch = e->d_epoch; fa.err = e->d_epoch + 1;
-      fa.gq = e->fq_gq + (size_t)li * H * FQ_QKV; fa.gp = e->fq_gp + (size_t)li * H * FQ_G * FQ_PART;
-      fa.out = e->ar_attn; fa.kcache = kc; fa.vcache = vc; fa.xnorm_out = a.xnorm_out;
-      fa.d = d; fa.nhead = H; fa.ctx_max = e->ctx_max; fa.scale = scale;
-      fa.pf = a.pf; fa.pf_slice = a.pf_slice; fa.pf_total = a.pf_total; fa.layer = li;
-      VXC(launch_fused(e, a.pro, a.W, a.x, a.gamma, a.beta, fa, s));
-      GemvArgs o{};
-      o.st = e->d_st;
-      o.W = l.out_w; o.bias = l.out_b; o.x = e->ar_attn; o.y = e->ar_x; o.N = d; o.K = d; o.pro = PRO_COPY; o.epi = EPI_RESID;
-      o.res = res;
-      warm(o, 4 * li + 1);
-      o.nt = ar_nt; o.kid = 3 + 5 * li;
-      VXC(launch_gemv(e->bf16, o, e->num_cu, s));
-    } else {
     VXC(launch_gemv(e->bf16, a, e->num_cu, s));
 #define AD(HDV)                                                                                                                                              \
   if (hd == HDV) {                                                                                                                                           \
@@ -1548,7 +1480,6 @@ static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
     warm(o, 4 * li + 1);
     o.nt = ar_nt; o.kid = 3 + 5 * li;
     VXC(launch_gemv(e->bf16, o, e->num_cu, s));
-    }
     // f = relu(linear1(LN2(x)))
     GemvArgs f{};
     f.st = e->d_st;
@@ -1776,11 +1707,11 @@ extern "C" int vx_ar_decode(vx_engine* e, const vx_decode_params* p, void* strea
   HIPC(hipMemcpyAsync(h_ep, e->d_epoch, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->es));
   HIPC(hipStreamSynchronize(e->es));
   HIPC(hipGetLastError());
-  if (h_ep[1] != 0) {  // a bounded spin of the fused launch ran out: its workgroups were not all resident (another process on the GPU?)
+  if (h_ep[1] != 0) {  // a bounded spin of the sharded step ran out: its workgroups were not all resident (another process on the GPU?)
     const unsigned code = h_ep[1];
     HIPC(hipMemsetAsync(e->d_epoch + 1, 0, sizeof(unsigned), e->es));
     HIPC(hipStreamSynchronize(e->es));
-    return fail(VX_ERR_STATE, "decode step: hand-over %u of the fused QKV + attention launch timed out (set VX_AR_FUSED=0)", code);
+    return fail(VX_ERR_STATE, "decode step: hand-over %u of the sharded decode step timed out (set VX_AR_TP=0)", code);
   }
   float ms = 0.f;
   HIPC(hipEventElapsedTime(&ms, e->ev_t[2], e->ev_t[3]));

@@ -228,7 +228,7 @@ extern "C" int vx_debug_kstamps(void* dst, int64_t nbytes, int32_t* dims) {
 #endif
 }
 
-// Stamps build only: phase times of the fused QKV + attention launch (ar_fused.hpp FQ_STAMP), [layer 16][workgroup 256][8] uint64 of
+// Stamps build only: phase times of the sharded decode step's launches (ar_tp.hpp TP_STAMP), [layer 16][workgroup 256][8] uint64 of
 // s_memrealtime (100 MHz).  dst == NULL arms (allocates + zeroes), otherwise copies out.
 extern "C" int vx_debug_fqstamps(void* dst, int64_t nbytes) {
 #ifdef VX_STAMPS

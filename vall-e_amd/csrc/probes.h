@@ -28,7 +28,7 @@ int vx_debug_read_stamps(unsigned long long* out, int32_t n);
  * [16 passes][64 kernel ids] uint64; a pass lands in slot pass % 16. */
 int vx_debug_kstamps(void* dst, int64_t nbytes, int32_t* dims);
 
-/* Stamps build only: phase times of the fused QKV + attention launch, [16 layers][256 workgroups][8] uint64 (100 MHz);
+/* Stamps build only: phase times of the sharded decode step's two launches, [2 kinds][16 layers][256 workgroups][16] uint64 (100 MHz);
  * dst == NULL arms. */
 int vx_debug_fqstamps(void* dst, int64_t nbytes);
 
