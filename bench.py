@@ -127,8 +127,8 @@ def cpu_baseline(sd, cfg, x, x_lens, y, budget_s: float):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", help="bf16 | fp32 (the token-exact parity mode) | fp8nar (bf16 AR, fp8 NAR GEMMs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per leg of the cpu_baseline sample")

@@ -34,8 +34,8 @@ def _compile(out: str, defines, verbose: bool) -> str:
     cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out] + [os.path.join(HERE, s) for s in SRCS]
     if os.environ.get("VX_SAVE_TEMPS"):
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
+    if verbose:  # to stderr: bench.py's stdout carries exactly one JSON line, and a stale library is rebuilt from there too
+        print(" ".join(cmd), file=sys.stderr, flush=True)
     subprocess.check_call(cmd, cwd=HERE)
     return out
 
