@@ -19,7 +19,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          # kernel arguments (the first 16 SGPRs' worth of explicit ones) arrive in registers at wave launch instead of by an
          # s_load the kernel's first instructions wait for: 0.3 us per dependent kernel of the decode step
-         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+         "-mllvm", "-amdgpu-kernarg-preload-count=16",
+         # MFMA accumulators in VGPRs wherever the kernel does not need the AGPR file for capacity: the flash-attention loop spent
+         # 128 of its ~280 VALU slots per key tile on v_accvgpr_read / _write copies (batched NAR stages 110.9 -> 107.7 ms)
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def stale(out: str = OUT) -> bool:

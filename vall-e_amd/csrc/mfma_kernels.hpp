@@ -1424,7 +1424,7 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
     // rescale the running sums only when some query's maximum moved (wave-uniform test; the factor is exactly 1
     // otherwise): after the first few key tiles it rarely does
     if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
-      const float corr = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);
+      const float corr = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_use) * 1.4426950408889634f);
       l_run *= corr;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -1432,16 +1432,26 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
         for (int v = 0; v < 16; ++v) accO[t][v] *= corr;
     }
     m_run = m_new;
-    // P^T = exp(S^T - m), cast to bf16 in accumulator order = B fragments of the next product
+    // P^T = exp(S^T - m) = exp2(S^T log2(e) - m log2(e)): one fma + v_exp_f32 per element (the exp's own range scaling and the
+    // separate multiply were 2 of the ~9 VALU slots per element of this loop, which is VALU-bound: 16 MFMAs against ~280 slots);
+    // row sums on packed adds; cast to bf16 in accumulator order = B fragments of the next product
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float m2 = m_use * LOG2E;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t l2 = {0.f, 0.f};
     bf16x8_t pf[2][2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const float p = __expf(accS[sub][v] - m_use);
-        l_run += p;
-        pf[sub][v >> 3][v & 7] = (bf16)p;
+      for (int v = 0; v < 16; v += 2) {
+        f32x2_t p2;
+        p2.x = __builtin_amdgcn_exp2f(fmaf(accS[sub][v], LOG2E, -m2));
+        p2.y = __builtin_amdgcn_exp2f(fmaf(accS[sub][v + 1], LOG2E, -m2));
+        l2 += p2;
+        pf[sub][v >> 3][v & 7] = (bf16)p2.x;
+        pf[sub][v >> 3][(v & 7) + 1] = (bf16)p2.y;
       }
+    l_run += l2.x + l2.y;
     // O^T += V^T . P^T : element j of half hh is key 16s + 8(j>>2) + 4hh + (j&3) of the sub-tile
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -1527,25 +1537,29 @@ static inline int mfma_attn_dispatch(const bf16* qkv, const bf16* vt, int vt_ld,
                                      int text_len, hipStream_t s, const int* seg_start = nullptr,
                                      const int* seg_len = nullptr, int nseg = 1, int max_seg_len = 0,
                                      const int* seg_text = nullptr) {
-  constexpr int NW = 2;
   const int rows = seg_start ? max_seg_len : M;
-  dim3 grid((rows + 32 * NW - 1) / (32 * NW), H, seg_start ? nseg : 1);
   // fewer than ~2 workgroups per CU: split the keys over two wave groups inside the workgroup (4 waves = all 4 SIMDs)
   static const int kgsel = [] { const char* v = getenv("VX_ATTN_KG"); return v ? atoi(v) : 0; }();  // A/B runs
+  static const int nwsel = [] { const char* v = getenv("VX_ATTN_NW"); return v ? atoi(v) : 0; }();  // A/B runs: query waves per workgroup
   static bool attr_dev[16] = {}; bool& attr_done = attr_dev[vx_cur_device()];
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)mfma_attn_kernel<NW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)mfma_attn_kernel<NW, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)mfma_attn_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)mfma_attn_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     attr_done = true;
   }
-  const long long nwg = (long long)grid.x * grid.y * grid.z;
-  const int kg = kgsel ? kgsel : (nwg < 512 ? 2 : 1);  // 4 groups measured slower than 2 at batch-1 NAR (10.7 vs 10.3 ms)
+  const long long nwg2 = (long long)((rows + 63) / 64) * H * (seg_start ? nseg : 1);
+  const int kg = kgsel ? kgsel : (nwg2 < 512 ? 2 : 1);  // 4 groups measured slower than 2 at batch-1 NAR (10.7 vs 10.3 ms)
+  // many workgroups (batched NAR / prefill): FOUR query waves share every staged K / V tile (128 query rows per workgroup)
+  const int nw = kg != 1 ? 2 : nwsel ? (nwsel == 4 ? 4 : 2) : (nwg2 >= 2048 ? 4 : 2);  // 8 waves: 105.4 vs 101.8 ms (profiles/r03_notes.md)
+  dim3 grid((rows + 32 * nw - 1) / (32 * nw), H, seg_start ? nseg : 1);
   if (kg == 4)
-    mfma_attn_kernel<NW, 4><<<grid, NW * 4 * 64, 131072, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
+    mfma_attn_kernel<2, 4><<<grid, 2 * 4 * 64, 131072, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
   else if (kg == 2)
-    mfma_attn_kernel<NW, 2><<<grid, NW * 2 * 64, 65536, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
+    mfma_attn_kernel<2, 2><<<grid, 2 * 2 * 64, 65536, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
+  else if (nw == 4)
+    mfma_attn_kernel<4, 1><<<grid, 4 * 64, 32768, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
   else
-    mfma_attn_kernel<NW, 1><<<grid, NW * 64, 32768, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
+    mfma_attn_kernel<2, 1><<<grid, 2 * 64, 32768, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
   return 0;
 }
 
