@@ -470,7 +470,8 @@ struct SampleArgs {
   // batched decode: workgroup = slot; per-slot strides (0 in the batch-1 step, grid = 1)
   int logits_stride, tok_stride;
   int kid;  // probe builds: VX_KSTAMP id (-1 = not stamped)
-  unsigned* epoch;  // batch-1 step: launch counter, bumped once per step whatever the decode state (tags the hand-overs of ar_fused.hpp)
+  unsigned* epoch;  // batch-1 step: launch counter, bumped once per step whatever the decode state (tags the hand-overs of ar_granules.hpp)
+  long long* zero_acc;  // sharded step: (1024,) int64 accumulator this launch zeroes for the step it opens (ar_tp.hpp), or null
 };
 
 __device__ __forceinline__ uint32_t order_key(float v) {
@@ -846,6 +847,10 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
   if (a.epoch != nullptr && tid == 0) {  // 0 is never a tag (fresh granules are zero-filled)
     const unsigned n = *a.epoch + 1u;
     *a.epoch = n ? n : 1u;
+  }
+  if (a.zero_acc != nullptr) {  // whatever the decode state: the step's launches run (and accumulate) on every replay
+    *reinterpret_cast<uint4*>(a.zero_acc + 4 * tid) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(a.zero_acc + 4 * tid + 2) = make_uint4(0u, 0u, 0u, 0u);
   }
   if (st->done) return;  // uniform
   sample4_body<NVT, NV0>(a, st, v, lg, slot);

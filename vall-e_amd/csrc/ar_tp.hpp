@@ -16,8 +16,8 @@
 //                   units.  Output: 8 partial vectors of linear2.
 //   tp_head_kernel  final norm of (x + bias + partials) and the 1025 logit rows.
 //
-// The cross-XCD sums travel over the launch boundary (the consumer adds the 8 partials in a fixed order: deterministic, no
-// atomics); everything inside a launch is tagged granules (ar_granules.hpp).  All weights of a launch are requested at its start,
+// The cross-XCD sums travel over the launch boundary as ONE vector: every workgroup adds its partial rows into a 64-bit FIXED-POINT
+// accumulator that carries the residual stream itself (integer adds commute: deterministic whatever the arrival order); everything inside a launch is tagged granules (ar_granules.hpp).  All weights of a launch are requested at its start,
 // so the in-launch stages pay a hop and their arithmetic, not a memory latency.  Placement (blockIdx % 8 == XCD) is a speed
 // assumption only: the granules are written through (sc1) and polled with sc1 loads, valid across XCDs.
 // Reference arithmetic: valle/modules/transformer.py:297-334 (pre-norm encoder layer), activation.py:407-427.
@@ -42,20 +42,31 @@ constexpr int TP_D = 1024, TP_H = 16, TP_FF = 4096, TP_X = 8, TP_WG = 32;  // mo
 constexpr int TP_HID = TP_FF / TP_X;   // hidden units per XCD
 constexpr int TP_ACH = TP_D / TP_X;    // attention channels per XCD (two heads)
 
-struct TpRowArgs {       // the row every workgroup of a launch normalises: x_in (+ bias + 8 partials)
-  float* x_out;          // workgroup 0 stores the summed residual stream here (never aliases x_in)
+// Residual stream between the launches of a step: 1024 x int64 fixed point (value x 2^32), three buffers in rotation.  Launch n
+// normalises buffer R = n % 3 (complete: the previous launch's adds and the launch boundary), adds its own output into
+// A = (n + 1) % 3 - every workgroup its 32 partial rows of the sharded GEMV, XCD 0's workgroups also the carry (the value of R)
+// and the GEMV's bias - and zeroes Z = (n + 2) % 3 for the launch after next.  One accumulator instead of eight partial
+// vectors + bias + x: the row every workgroup reads shrinks from 12 loads per thread to 4 (2 x int64 quads, gamma, beta) - with all
+// 128 waves of an XCD asking its L2 for the same lines at the same moment that is what the row's latency follows
+// (12 -> 4 loads: 213.5 -> 204.6 us per token in a timing-only experiment, profiles/r03_notes.md).  Exactness: a partial p is added
+// as rint(p 2^32); the sums are exact integers, the residual stream is rounded to fp32 once, where a norm reads it.
+struct TpAccArgs {
+  long long* add;          // A: this launch's output accumulates here
+  long long* zero;         // Z: zeroed by workgroup 1
+  const float* bias;       // bias of this launch's sharded GEMV (out-projection / linear2), added once (by XCD 0)
 };
+constexpr float TP_FIX = 4294967296.0f, TP_UNFIX = 2.3283064365386963e-10f;
+__device__ __forceinline__ long long tp_fix(float v) { return __float2ll_rn(v * TP_FIX); }
 // The LayerNorm affine and the bias that arrives with the partials travel as ONE (3, 1024) block {gamma, beta, bias} per norm
 // site (packed at vx_finalize_weights), so that a single preloaded pointer reaches them: their loads go out with the row's,
 // in front of the weight stream (vmcnt retires in order - behind the weights the norm would wait for the whole stream).
 
 struct TpAttnArgs {
-  TpRowArgs row;
   const float* qkv_bias;   // (3d,)
   unsigned* err;
   fq_gran* gq;             // this layer's (16, FQ_QKV)
   fq_gran* gp;             // this layer's (16, FQ_G, FQ_PART)
-  float* part_out;         // (8, d) partial sums of the out-projection
+  TpAccArgs acc;
   void* kcache;
   void* vcache;
   int ctx_max;
@@ -64,22 +75,20 @@ struct TpAttnArgs {
 };
 
 struct TpFfnArgs {
-  TpRowArgs row;
   const float* b1;         // (4d,)
   unsigned* err;
   fq_gran* gh;             // this layer's (8, TP_HID)
-  float* part_out;         // (8, d) partial sums of linear2
+  TpAccArgs acc;
   int layer;
 };
 
 struct TpHeadArgs {
-  TpRowArgs row;
   float* logits;
   int N;
 };
 
-// x = x_in + bias + p_0 + ... + p_7 (fixed order), LayerNorm over the 1024 channels by the whole workgroup (thread t owns
-// channels 4t..4t+3), result in LDS.  Every load is issued before the first wait.  `red` = 8 floats of LDS.
+// Row prologue: the residual row (fp32 embedding or the int64 accumulator), LayerNorm over the 1024 channels by the whole workgroup
+// (thread t owns channels 4t..4t+3), result in LDS.  Every load is issued before the first wait.  `red` = 8 floats of LDS.
 // Every global load of a launch's prologue is an asm statement: volatile asm keeps source order, so the ROW's loads really are
 // the first in the queue (left to the compiler they were scheduled behind the whole weight stream - vmcnt retires in order, and
 // the norm waited for 16 MB of weights), and the counted waits below are exact by construction: tp_wait<N> = "at most N of the
@@ -104,52 +113,38 @@ template <int N> __device__ __forceinline__ void tp_wait(vx_u32x4& a) { asm vola
 template <int N> __device__ __forceinline__ void tp_wait(float& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
 __device__ __forceinline__ uint4 tp_u4(const vx_u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); }
 
-struct TpRowLoads { tp_f4 x, b, g, be, p[TP_X]; };
-template <bool PARTS>
-__device__ __forceinline__ void tp_row_issue(TpRowLoads& r, const float* __restrict__ x_in, const float* __restrict__ part,
+struct TpRowLoads { tp_f4 x, g, be; vx_u32x4 xf[2]; };
+// FIRST: the row is the sampler's fp32 embedding vector (layer 0's attention half); otherwise four int64 of the accumulator R
+template <bool FIRST>
+__device__ __forceinline__ void tp_row_issue(TpRowLoads& r, const float* __restrict__ x_f32, const long long* __restrict__ racc,
                                              const float* __restrict__ gbb, int tid) {
-#ifdef TP_EXP_STATIC_FIRST  // timing experiment: the static norm parameters first, the freshly written vectors behind them
-  tp_ld16f(r.g, gbb + 4 * tid);
-  tp_ld16f(r.be, gbb + TP_D + 4 * tid);
-  tp_ld16f(r.x, x_in + 4 * tid);
-  if (PARTS) {
-#pragma unroll
-    for (int s = 0; s < TP_X; ++s) tp_ld16f(r.p[s], part + (size_t)s * TP_D + 4 * tid);
-    tp_ld16f(r.b, gbb + 2 * TP_D + 4 * tid);
-  }
-#else
-  tp_ld16f(r.x, x_in + 4 * tid);
-  if (PARTS) {
-#pragma unroll
-    for (int s = 0; s < TP_X; ++s) tp_ld16f(r.p[s], part + (size_t)s * TP_D + 4 * tid);
-    tp_ld16f(r.b, gbb + 2 * TP_D + 4 * tid);
+  if (FIRST) {
+    tp_ld16f(r.x, x_f32 + 4 * tid);
+  } else {
+    tp_ld16(r.xf[0], racc + 4 * tid);
+    tp_ld16(r.xf[1], racc + 4 * tid + 2);
   }
   tp_ld16f(r.g, gbb + 4 * tid);
   tp_ld16f(r.be, gbb + TP_D + 4 * tid);
-#endif
 }
 // AFTER = loads issued behind the row's
-template <bool PARTS, int AFTER> __device__ __forceinline__ void tp_row_wait(TpRowLoads& r) {
-  if (PARTS)
-    asm volatile("s_waitcnt vmcnt(%12)" : "+v"(r.x), "+v"(r.b), "+v"(r.g), "+v"(r.be), "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]),
-                 "+v"(r.p[4]), "+v"(r.p[5]), "+v"(r.p[6]), "+v"(r.p[7]) : "n"(AFTER) : "memory");
-  else
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.x), "+v"(r.g), "+v"(r.be) : "n"(AFTER) : "memory");
+template <bool FIRST, int AFTER> __device__ __forceinline__ void tp_row_wait(TpRowLoads& r) {
+  if (FIRST) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.x), "+v"(r.g), "+v"(r.be) : "n"(AFTER) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.xf[0]), "+v"(r.xf[1]), "+v"(r.g), "+v"(r.be) : "n"(AFTER) : "memory");
+}
+__device__ __forceinline__ float tp_unfix(unsigned lo, unsigned hi) {
+  return __ll2float_rn((long long)(((unsigned long long)hi << 32) | lo)) * TP_UNFIX;
 }
 template <typename WT> __device__ __forceinline__ float tp_exp(float v) {  // fp32 engine: the precise exp of the plain kernels
   if constexpr (std::is_same<WT, float>::value) return expf(v);
   else return __expf(v);
 }
-template <bool PARTS>
-__device__ __forceinline__ void tp_row_norm(TpRowLoads& r, const TpRowArgs& a, float* xs, float* red, int tid) {
+template <bool FIRST>
+__device__ __forceinline__ void tp_row_norm(TpRowLoads& r, float* xs, float* red, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
-  float4 v = make_float4(r.x.x, r.x.y, r.x.z, r.x.w);
-  if (PARTS) {
-    v.x += r.b.x; v.y += r.b.y; v.z += r.b.z; v.w += r.b.w;
-#pragma unroll
-    for (int s = 0; s < TP_X; ++s) { v.x += r.p[s].x; v.y += r.p[s].y; v.z += r.p[s].z; v.w += r.p[s].w; }
-    if (blockIdx.x == 0) *reinterpret_cast<float4*>(a.x_out + 4 * tid) = v;
-  }
+  float4 v;
+  if (FIRST) v = make_float4(r.x.x, r.x.y, r.x.z, r.x.w);
+  else v = make_float4(tp_unfix(r.xf[0].x, r.xf[0].y), tp_unfix(r.xf[0].z, r.xf[0].w), tp_unfix(r.xf[1].x, r.xf[1].y), tp_unfix(r.xf[1].z, r.xf[1].w));
   float s1 = wave_sum_dpp((v.x + v.y) + (v.z + v.w));
   if (lane == 0) red[wave] = s1;
   __syncthreads();
@@ -162,6 +157,22 @@ __device__ __forceinline__ void tp_row_norm(TpRowLoads& r, const TpRowArgs& a, f
   *reinterpret_cast<float4*>(xs + 4 * tid) =
       make_float4(d0 * rstd * r.g.x + r.be.x, d1 * rstd * r.g.y + r.be.y, d2 * rstd * r.g.z + r.be.z, d3 * rstd * r.g.w + r.be.w);
   __syncthreads();
+}
+
+// The tail of both halves: row 32i + tid/8 of the sharded GEMV's partial (in lanes tid % 8 == 0) goes into the accumulator;
+// XCD 0 also adds the carry and the bias (requested in the prologue: `carry` = R's word / the fp32 embedding, `bo` = bias).
+template <bool FIRST>
+__device__ __forceinline__ void tp_acc_tail(const TpAccArgs& a, float partial, int xcd, int i, int tid, unsigned long long carry_ll,
+                                            float carry_f, float bo) {
+  if ((tid & 7) == 0) {
+    long long add = tp_fix(partial);
+    if (xcd == 0) add += tp_fix(bo) + (FIRST ? tp_fix(carry_f) : (long long)carry_ll);
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.add) + 32 * i + (tid >> 3), (unsigned long long)add);
+  }
+  if (blockIdx.x == 1) {
+    *reinterpret_cast<uint4*>(a.zero + 4 * tid) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(a.zero + 4 * tid + 2) = make_uint4(0u, 0u, 0u, 0u);
+  }
 }
 
 // lane's slice of the normalised row in the GEMV layout: chunk c holds channels (c * 64 + lane) * VEC .. + VEC
@@ -192,9 +203,9 @@ __device__ __forceinline__ float tp_dot(const uint4 (&w)[KCH], const float (&xr)
 // ------------------------------------------------------------------------------------------------ attention half
 // Wo_ = this layer's out-projection re-laid out by tp_repack_kernel: [x][i][m][t] 16-byte words, word (m, t) = row 32i + t/8,
 // channels 128x + (t%8 + 8m) * VEC .. + VEC.
-template <typename WT, bool PARTS>
-__global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ Wqkv_, const float* __restrict__ x_in,
-                                                      const float* __restrict__ part_in, const float* __restrict__ gbb,
+template <typename WT, bool FIRST>
+__global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ Wqkv_, const float* __restrict__ x_f32,
+                                                      const long long* __restrict__ racc, const float* __restrict__ gbb,
                                                       const ArState* __restrict__ st, const unsigned* __restrict__ epoch,
                                                       const void* __restrict__ Wo_, const TpAttnArgs a) {
   constexpr int VEC = Vec16<WT>::N;
@@ -222,7 +233,7 @@ __global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ W
 
   // ---- every load of the launch, in this order, before the first wait ----
   TpRowLoads rl;
-  tp_row_issue<PARTS>(rl, x_in, part_in, gbb, tid);
+  tp_row_issue<FIRST>(rl, x_f32, racc, gbb, tid);
   TP_STAMP(0, 0);
   vx_u32x4 w[3][KCH];
 #pragma unroll
@@ -235,6 +246,12 @@ __global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ W
     asm volatile("" : "+s"(bp));
     tp_ld4f(e_bias, bp + min(lane, 2) * TP_D + ch);
   }
+  // the accumulator tail's operands of row 32i + tid/8 (used by XCD 0 only; requested by all: the counted waits stay uniform)
+  unsigned long long carry_ll = 0ull;
+  float carry_f = 0.f, bo;
+  if (FIRST) tp_ld4f(carry_f, x_f32 + 32 * i + (tid >> 3));
+  else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(carry_ll) : "v"(racc + 32 * i + (tid >> 3)) : "memory");
+  tp_ld4f(bo, a.acc.bias + 32 * i + (tid >> 3));
   // second-stage operands: the out-projection slice and this split's cached keys
   const int n_old = st_row;  // the newest row travels in the granules
   const int chunk = (n_old + FQ_G - 1) / FQ_G;
@@ -274,16 +291,9 @@ __global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ W
   constexpr int N_KV = 2 * UNR, N_WO = OCH, N_W = 3 * KCH;
 
   // ---- LN1, the three dot products, publish ----
-#ifdef VX_STAMPS
-#ifdef TP_EXP_STATIC_FIRST
-  if (PARTS) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rl.g) : "n"(11 + N_W + 1 + N_WO + N_KV) : "memory"); TP_STAMP(0, 12); }
-#else
-  if (PARTS) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rl.x) : "n"(11 + N_W + 1 + N_WO + N_KV) : "memory"); TP_STAMP(0, 12); }
-#endif
-#endif
-  tp_row_wait<PARTS, N_W + 1 + N_WO + N_KV>(rl);
+  tp_row_wait<FIRST, N_W + 3 + N_WO + N_KV>(rl);
   TP_STAMP(0, 7);
-  tp_row_norm<PARTS>(rl, a.row, xs, red, tid);
+  tp_row_norm<FIRST>(rl, xs, red, tid);
   TP_STAMP(0, 1);
   {
     float xr[KCH][VEC];
@@ -293,10 +303,10 @@ __global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ W
     for (int r = 0; r < 3; ++r) {
       uint4 wr[KCH];
 #pragma unroll
-      for (int c = 0; c < KCH; ++c) { tp_wait<N_WO + N_KV + 1>(w[r][c]); wr[c] = tp_u4(w[r][c]); }
+      for (int c = 0; c < KCH; ++c) { tp_wait<N_WO + N_KV + 3>(w[r][c]); wr[c] = tp_u4(w[r][c]); }
       acc[r] = wave_sum_dpp(tp_dot<WT, KCH>(wr, xr));
     }
-    tp_wait<N_WO + N_KV>(e_bias);
+    tp_wait<N_WO + N_KV + 2>(e_bias);
     if (lane < 3) {
       float v = (lane == 0 ? acc[0] : lane == 1 ? acc[1] : acc[2]) + e_bias;
       if (lane > 0) {  // K / V travel rounded to the cache's element type: the values later passes read back
@@ -321,6 +331,7 @@ __global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ W
   for (int u = 0; u < UNR; ++u) { tp_wait<0>(kr[u]); tp_wait<0>(vr[u]); }  // the gather waited for everything
 #pragma unroll
   for (int m = 0; m < OCH; ++m) tp_wait<0>(wo[m]);
+  asm volatile("" : "+v"(carry_ll), "+v"(carry_f), "+v"(bo));
   TP_STAMP(0, 3);
   __syncthreads();
   TP_STAMP(0, 8);
@@ -460,7 +471,7 @@ __global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ W
       for (int c = 0; c < VEC; ++c) s = fmaf(wf[c], ap[c], s);
     }
     s = group8_sum_dpp(s);
-    if ((tid & 7) == 0) a.part_out[(size_t)x * TP_D + 32 * i + (tid >> 3)] = s;
+    tp_acc_tail<FIRST>(a.acc, s, x, i, tid, carry_ll, carry_f, bo);
   }
   TP_STAMP(0, 6);
 }
@@ -469,8 +480,8 @@ __global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ W
 // W2_ = this layer's linear2 re-laid out by tp_repack_kernel: [x][i][m][t], word (m, t) = row 32i + t/8, hidden units
 // 512x + (t%8 + 8m) * VEC .. + VEC.
 template <typename WT>
-__global__ __launch_bounds__(256) void tp_ffn_kernel(const void* __restrict__ W1_, const float* __restrict__ x_in,
-                                                     const float* __restrict__ part_in, const float* __restrict__ gbb,
+__global__ __launch_bounds__(256) void tp_ffn_kernel(const void* __restrict__ W1_, const long long* __restrict__ racc,
+                                                     const float* __restrict__ gbb,
                                                      const unsigned* __restrict__ epoch, const void* __restrict__ W2_,
                                                      const TpFfnArgs a) {
   constexpr int VEC = Vec16<WT>::N;
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(256) void tp_ffn_kernel(const void* __restrict__ W1
   const int row0 = TP_HID * x + 16 * i + 4 * wave;  // this wave's four hidden units
 
   TpRowLoads rl;
-  tp_row_issue<true>(rl, x_in, part_in, gbb, tid);
+  tp_row_issue<false>(rl, nullptr, racc, gbb, tid);
   TP_STAMP(1, 0);
   vx_u32x4 w1[4][KCH];
 #pragma unroll
@@ -499,6 +510,10 @@ __global__ __launch_bounds__(256) void tp_ffn_kernel(const void* __restrict__ W1
     asm volatile("" : "+s"(bp));
     tp_ld4f(e_b1, bp + row0 + min(lane, 3));
   }
+  unsigned long long carry_ll;
+  float bo;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(carry_ll) : "v"(racc + 32 * i + (tid >> 3)) : "memory");
+  tp_ld4f(bo, a.acc.bias + 32 * i + (tid >> 3));
   vx_u32x4 w2[FCH];
   auto tp_stage2 = [&]() {
     const uint4* wb = reinterpret_cast<const uint4*>(W2_) + (size_t)(x * TP_WG + i) * FCH * 256;
@@ -506,9 +521,9 @@ __global__ __launch_bounds__(256) void tp_ffn_kernel(const void* __restrict__ W1
     for (int m = 0; m < FCH; ++m) tp_ld16w(w2[m], wb + m * 256 + tid);
   };
   tp_stage2();
-  tp_row_wait<true, 4 * KCH + 1 + FCH>(rl);
+  tp_row_wait<false, 4 * KCH + 3 + FCH>(rl);
   TP_STAMP(1, 7);
-  tp_row_norm<true>(rl, a.row, xs, red, tid);
+  tp_row_norm<false>(rl, xs, red, tid);
   TP_STAMP(1, 1);
   {
     float xr[KCH][VEC];
@@ -518,10 +533,10 @@ __global__ __launch_bounds__(256) void tp_ffn_kernel(const void* __restrict__ W1
     for (int r = 0; r < 4; ++r) {
       uint4 wr[KCH];
 #pragma unroll
-      for (int c = 0; c < KCH; ++c) { tp_wait<1 + FCH>(w1[r][c]); wr[c] = tp_u4(w1[r][c]); }
+      for (int c = 0; c < KCH; ++c) { tp_wait<3 + FCH>(w1[r][c]); wr[c] = tp_u4(w1[r][c]); }
       acc[r] = wave_sum_dpp(tp_dot<WT, KCH>(wr, xr));
     }
-    tp_wait<FCH>(e_b1);
+    tp_wait<2 + FCH>(e_b1);
     if (lane < 4) {
       const float v = (lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3]) + e_b1;
       gran_store(a.gh + (size_t)x * TP_HID + 16 * i + 4 * wave + lane, fmaxf(v, 0.f), tag);
@@ -535,6 +550,7 @@ __global__ __launch_bounds__(256) void tp_ffn_kernel(const void* __restrict__ W1
   }
 #pragma unroll
   for (int m = 0; m < FCH; ++m) tp_wait<0>(w2[m]);  // the gather waited for everything
+  asm volatile("" : "+v"(carry_ll), "+v"(bo));
   TP_STAMP(1, 3);
   __syncthreads();
   {
@@ -548,7 +564,7 @@ __global__ __launch_bounds__(256) void tp_ffn_kernel(const void* __restrict__ W1
       for (int c = 0; c < VEC; ++c) s = fmaf(wf[c], hp[c], s);
     }
     s = group8_sum_dpp(s);
-    if ((tid & 7) == 0) a.part_out[(size_t)x * TP_D + 32 * i + (tid >> 3)] = s;
+    tp_acc_tail<false>(a.acc, s, x, i, tid, carry_ll, 0.f, bo);
   }
   TP_STAMP(1, 4);
 }
@@ -556,8 +572,8 @@ __global__ __launch_bounds__(256) void tp_ffn_kernel(const void* __restrict__ W1
 // ------------------------------------------------------------------------------------------------ head
 // logits = ar_predict_layer(norm(x + bias + partials)) (valle.py:1039): 4 rows per wave, grid = ceil(N / 16).
 template <typename WT>
-__global__ __launch_bounds__(256) void tp_head_kernel(const void* __restrict__ W_, const float* __restrict__ x_in,
-                                                      const float* __restrict__ part_in, const float* __restrict__ gbb,
+__global__ __launch_bounds__(256) void tp_head_kernel(const void* __restrict__ W_, const long long* __restrict__ racc,
+                                                      const float* __restrict__ gbb,
                                                       const ArState* __restrict__ st, const TpHeadArgs a) {
   constexpr int VEC = Vec16<WT>::N;
   constexpr int KCH = TP_D / (64 * VEC);
@@ -567,15 +583,15 @@ __global__ __launch_bounds__(256) void tp_head_kernel(const void* __restrict__ W
   const WT* __restrict__ W = reinterpret_cast<const WT*>(W_);
   const int row0 = (blockIdx.x * 4 + wave) * 4;
   TpRowLoads rl;
-  tp_row_issue<true>(rl, x_in, part_in, gbb, tid);
+  tp_row_issue<false>(rl, nullptr, racc, gbb, tid);
   vx_u32x4 w[4][KCH];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int c = 0; c < KCH; ++c) tp_ld16w(w[r][c], W + (size_t)min(row0 + r, a.N - 1) * TP_D + (c * 64 + lane) * VEC);
   const int st_pass = st->pass, st_trace = st->trace_logits, st_done = st->done;
-  tp_row_wait<true, 4 * KCH>(rl);
-  tp_row_norm<true>(rl, a.row, xs, red, tid);
+  tp_row_wait<false, 4 * KCH>(rl);
+  tp_row_norm<false>(rl, xs, red, tid);
   float xr[KCH][VEC];
   tp_row_read<KCH, VEC>(xs, lane, xr);
   float acc[4];

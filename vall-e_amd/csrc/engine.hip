@@ -126,7 +126,7 @@ struct vx_engine {
   // partial-sum vectors of the two sharded GEMVs, the second residual buffer, the hidden-unit granules
   bool tp = false;
   std::vector<void*> tp_wo, tp_w2;
-  float *tp_part_o = nullptr, *tp_part_f = nullptr, *tp_x1 = nullptr;
+  long long* tp_xacc = nullptr;  // (3, d) int64 fixed-point residual accumulators in rotation (ar_tp.hpp TpAccArgs)
   float* tp_gbb = nullptr;  // (2 L + 1, 3, d): {gamma, beta, arriving bias} per norm site of the step
   fq_gran* tp_gh = nullptr;
   fq_gran *fq_gq = nullptr, *fq_gp = nullptr;
@@ -799,17 +799,13 @@ static int tp_setup(vx_engine* e) {
   }
   if ((long long)(n1 < n2 ? n1 : n2) * e->num_cu < TP_X * TP_WG) return VX_OK;
   const size_t L = (size_t)c.num_layers;
-  VXC(dalloc_t(e, &e->tp_part_o, (size_t)TP_X * TP_D));
-  VXC(dalloc_t(e, &e->tp_part_f, (size_t)TP_X * TP_D));
-  VXC(dalloc_t(e, &e->tp_x1, (size_t)TP_D));
+  VXC(dalloc_t(e, &e->tp_xacc, (size_t)3 * TP_D));
   VXC(dalloc_t(e, &e->tp_gh, L * TP_X * TP_HID));
   VXC(dalloc_t(e, &e->tp_gbb, (2 * L + 1) * 3 * TP_D));
   VXC(dalloc_t(e, &e->fq_gq, L * H * FQ_QKV));
   VXC(dalloc_t(e, &e->fq_gp, L * H * FQ_G * FQ_PART));
   HIPC(hipMemset(e->tp_gbb, 0, (2 * L + 1) * 3 * TP_D * 4));
-  HIPC(hipMemset(e->tp_part_o, 0, (size_t)TP_X * TP_D * 4));
-  HIPC(hipMemset(e->tp_part_f, 0, (size_t)TP_X * TP_D * 4));
-  HIPC(hipMemset(e->tp_x1, 0, (size_t)TP_D * 4));
+  HIPC(hipMemset(e->tp_xacc, 0, (size_t)3 * TP_D * sizeof(long long)));
   HIPC(hipMemset(e->tp_gh, 0, L * TP_X * TP_HID * sizeof(fq_gran)));  // zero tags: never equal to a step counter (starts at 1)
   HIPC(hipMemset(e->fq_gq, 0, L * H * FQ_QKV * sizeof(fq_gran)));
   HIPC(hipMemset(e->fq_gp, 0, L * H * FQ_G * FQ_PART * sizeof(fq_gran)));
@@ -1345,44 +1341,45 @@ extern "C" int vx_batch_prefill_all(vx_engine* e, int32_t n, const int64_t* cons
 // token, produce the next logits.  Every kernel reads its position from e->d_st, so the same
 // launch sequence (captured once as a hipGraph) serves every pass.
 static int enqueue_ar_step_f(vx_engine* e, hipStream_t s);
-// The layers and the head of the XCD-sharded step (ar_tp.hpp); the sampling launch in front of them is the caller's.
-// Residual stream: ar_x (the fresh embedding) -> tp_x1 after layer 0's feed-forward half; from then on the attention half
-// reads tp_x1 and leaves the sum in ar_x, the feed-forward half reads ar_x and leaves it in tp_x1.
+// The layers and the head of the XCD-sharded step (ar_tp.hpp); the sampling launch in front of them is the caller's (it writes
+// the fp32 embedding into ar_x and zeroes accumulator 1).  Launch n = 2 li (attention half), 2 li + 1 (feed-forward half), 2 L
+// (head) normalises accumulator n % 3, adds into (n + 1) % 3 and zeroes (n + 2) % 3; layer 0's attention half reads ar_x instead.
 static int enqueue_ar_step_tp(vx_engine* e, hipStream_t s) {
   const vx_config& c = e->cfg;
-  const int H = c.nhead, hd = c.d_model / H;
+  const int H = c.nhead, hd = c.d_model / H, L = c.num_layers;
   const size_t kv_layer = (size_t)2 * H * e->ctx_max * hd * e->esz;
   const int grid = TP_X * TP_WG;
-  for (int li = 0; li < c.num_layers; ++li) {
+  auto acc = [&](int n) { return e->tp_xacc + (size_t)(n % 3) * TP_D; };
+  for (int li = 0; li < L; ++li) {
     const LayerW& l = e->ar_l[li];
     char* kc = (char*)e->kv + (size_t)li * kv_layer;
+    const int n = 2 * li;
     TpAttnArgs a{};
-    a.row.x_out = e->ar_x;
     const float* gbb = e->tp_gbb + (size_t)(2 * li) * 3 * TP_D;
     a.qkv_bias = l.in_b; a.err = e->d_epoch + 1;
     a.gq = e->fq_gq + (size_t)li * H * FQ_QKV; a.gp = e->fq_gp + (size_t)li * H * FQ_G * FQ_PART;
-    a.part_out = e->tp_part_o; a.kcache = kc; a.vcache = kc + kv_layer / 2; a.ctx_max = e->ctx_max;
+    a.acc.add = acc(n + 1); a.acc.zero = acc(n + 2); a.acc.bias = l.out_b;
+    a.kcache = kc; a.vcache = kc + kv_layer / 2; a.ctx_max = e->ctx_max;
     a.scale = 1.0f / sqrtf((float)hd); a.layer = li;
-    const float* xin = li ? e->tp_x1 : e->ar_x;
     if (e->bf16) {
-      if (li) tp_attn_kernel<bf16, true><<<grid, 256, 0, s>>>(l.in_w, xin, e->tp_part_f, gbb, e->d_st, e->d_epoch, e->tp_wo[li], a);
-      else tp_attn_kernel<bf16, false><<<grid, 256, 0, s>>>(l.in_w, xin, e->tp_part_f, gbb, e->d_st, e->d_epoch, e->tp_wo[li], a);
+      if (li) tp_attn_kernel<bf16, false><<<grid, 256, 0, s>>>(l.in_w, e->ar_x, acc(n), gbb, e->d_st, e->d_epoch, e->tp_wo[li], a);
+      else tp_attn_kernel<bf16, true><<<grid, 256, 0, s>>>(l.in_w, e->ar_x, acc(n), gbb, e->d_st, e->d_epoch, e->tp_wo[li], a);
     } else {
-      if (li) tp_attn_kernel<float, true><<<grid, 256, 0, s>>>(l.in_w, xin, e->tp_part_f, gbb, e->d_st, e->d_epoch, e->tp_wo[li], a);
-      else tp_attn_kernel<float, false><<<grid, 256, 0, s>>>(l.in_w, xin, e->tp_part_f, gbb, e->d_st, e->d_epoch, e->tp_wo[li], a);
+      if (li) tp_attn_kernel<float, false><<<grid, 256, 0, s>>>(l.in_w, e->ar_x, acc(n), gbb, e->d_st, e->d_epoch, e->tp_wo[li], a);
+      else tp_attn_kernel<float, true><<<grid, 256, 0, s>>>(l.in_w, e->ar_x, acc(n), gbb, e->d_st, e->d_epoch, e->tp_wo[li], a);
     }
     TpFfnArgs f{};
-    f.row.x_out = e->tp_x1;
-    f.b1 = l.b1; f.err = e->d_epoch + 1; f.gh = e->tp_gh + (size_t)li * TP_X * TP_HID; f.part_out = e->tp_part_f; f.layer = li;
-    if (e->bf16) tp_ffn_kernel<bf16><<<grid, 256, 0, s>>>(l.w1, e->ar_x, e->tp_part_o, gbb + 3 * TP_D, e->d_epoch, e->tp_w2[li], f);
-    else tp_ffn_kernel<float><<<grid, 256, 0, s>>>(l.w1, e->ar_x, e->tp_part_o, gbb + 3 * TP_D, e->d_epoch, e->tp_w2[li], f);
+    f.b1 = l.b1; f.err = e->d_epoch + 1; f.gh = e->tp_gh + (size_t)li * TP_X * TP_HID; f.layer = li;
+    f.acc.add = acc(n + 2); f.acc.zero = acc(n + 3); f.acc.bias = l.b2;
+    if (e->bf16) tp_ffn_kernel<bf16><<<grid, 256, 0, s>>>(l.w1, acc(n + 1), gbb + 3 * TP_D, e->d_epoch, e->tp_w2[li], f);
+    else tp_ffn_kernel<float><<<grid, 256, 0, s>>>(l.w1, acc(n + 1), gbb + 3 * TP_D, e->d_epoch, e->tp_w2[li], f);
   }
   TpHeadArgs h{};
-  h.row.x_out = e->ar_xn;  // the final residual sum: nothing reads it
   h.logits = e->ar_logits; h.N = AR_VOCAB;
   const int hg = (AR_VOCAB + 15) / 16;
-  if (e->bf16) tp_head_kernel<bf16><<<hg, 256, 0, s>>>(W<void>(e, "ar_predict_layer.weight"), e->tp_x1, e->tp_part_f, e->tp_gbb + (size_t)(2 * c.num_layers) * 3 * TP_D, e->d_st, h);
-  else tp_head_kernel<float><<<hg, 256, 0, s>>>(W<void>(e, "ar_predict_layer.weight"), e->tp_x1, e->tp_part_f, e->tp_gbb + (size_t)(2 * c.num_layers) * 3 * TP_D, e->d_st, h);
+  const float* gbh = e->tp_gbb + (size_t)(2 * L) * 3 * TP_D;
+  if (e->bf16) tp_head_kernel<bf16><<<hg, 256, 0, s>>>(W<void>(e, "ar_predict_layer.weight"), acc(2 * L), gbh, e->d_st, h);
+  else tp_head_kernel<float><<<hg, 256, 0, s>>>(W<void>(e, "ar_predict_layer.weight"), acc(2 * L), gbh, e->d_st, h);
   return VX_OK;
 }
 
@@ -1397,6 +1394,7 @@ static SampleArgs step_sample_args(vx_engine* e) {
   if (c.flags & VX_FLAG_PRENET) { sa.alpha = e->d_zero; sa.x = e->ar_e; }  // raw embedding; the position is added after the prenet
   sa.kid = 0;  // stamp ids of the step (probe builds): 0 sampling, 1 + 5 l + {0 QKV, 1 attention, 2 out-proj, 3 FFN1, 4 FFN2}, 61 head
   sa.epoch = e->d_epoch;
+  sa.zero_acc = e->tp ? e->tp_xacc + TP_D : nullptr;  // accumulator 1: layer 0's attention half adds into it
   return sa;
 }
 static int enqueue_ar_step(vx_engine* e, hipStream_t s) {
