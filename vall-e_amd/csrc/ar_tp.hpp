@@ -1,25 +1,27 @@
 // Batch-1 decode step sharded over the 8 XCDs of the chip: TWO launches per layer instead of five.
 //
-// What a launch boundary costs on this part (1.65 us floor + a fabric round trip for the vector the previous launch wrote,
-// 3.2-4.5 us per dependent launch in situ, profiles/r02_notes.md) is what an exchange between workgroups on DIFFERENT XCDs
+// What a launch boundary costs on this part (1.5-1.8 us + a first load that returns 2.1-2.9 us after it was issued, ~3.8 us per
+// dependent launch before it has a single byte, profiles/r03_notes.md) is what an exchange between workgroups on DIFFERENT XCDs
 // costs whichever way it is done - but an exchange among the 32 workgroups of ONE XCD goes through that XCD's L2 and costs
-// 0.35-0.6 us (measured in situ, profiles/r03_notes.md).  So the layer is cut like a tensor-parallel
-// transformer over 8 devices, an XCD playing the device (d = 1024, 16 heads; workgroup b: XCD x = b % 8, local index i = b / 8):
+// 0.35-0.6 us (measured in situ).  So the layer is cut like a tensor-parallel transformer over 8 devices, an XCD playing the
+// device (d = 1024, 16 heads; workgroup b: XCD x = b % 8, local index i = b / 8):
 //
-//   tp_attn_kernel  XCD x owns heads 2x, 2x+1.   LN1 of the full row (every workgroup, cooperatively), the 12 q / k / v rows
+//   tp_attn_kernel  XCD x owns heads 2x, 2x+1.   LN1 of the residual row (every workgroup, cooperatively), the 12 q / k / v rows
 //                   of its quarter-head slice, [exchange inside the head: 192 values], attention over one sixteenth of the
 //                   cached keys (requested at kernel start), [exchange inside the XCD: the 2 x 16 partial softmaxes], combine,
-//                   and the XCD's K-slice of the out-projection: rows 32i..32i+31 over the 128 channels of its two heads.
-//                   Output: 8 partial vectors (one per XCD) of the out-projection.
-//   tp_ffn_kernel   LN2 of (x + bias + the 8 partials), XCD x owns hidden units 512x..512x+511: 16 FFN1 rows per workgroup,
+//                   and the XCD's K-slice of the out-projection: rows 32i..32i+31 over the 128 channels of its two heads,
+//                   added into the residual accumulator.
+//   tp_ffn_kernel   LN2 of the residual row, XCD x owns hidden units 512x..512x+511: 16 FFN1 rows per workgroup,
 //                   [exchange inside the XCD: 512 values], the XCD's K-slice of FFN2: rows 32i..32i+31 over its 512 hidden
-//                   units.  Output: 8 partial vectors of linear2.
-//   tp_head_kernel  final norm of (x + bias + partials) and the 1025 logit rows.
+//                   units, added into the residual accumulator.
+//   tp_head_kernel  final norm of the residual row and the 1025 logit rows.
 //
-// The cross-XCD sums travel over the launch boundary as ONE vector: every workgroup adds its partial rows into a 64-bit FIXED-POINT
-// accumulator that carries the residual stream itself (integer adds commute: deterministic whatever the arrival order); everything inside a launch is tagged granules (ar_granules.hpp).  All weights of a launch are requested at its start,
-// so the in-launch stages pay a hop and their arithmetic, not a memory latency.  Placement (blockIdx % 8 == XCD) is a speed
-// assumption only: the granules are written through (sc1) and polled with sc1 loads, valid across XCDs.
+// The cross-XCD sums travel over the launch boundary as ONE vector: every workgroup adds its partial rows into a 64-bit
+// FIXED-POINT accumulator that carries the residual stream itself (TpAccArgs: integer adds commute, so the result is
+// bit-reproducible whatever the arrival order).  Everything inside a launch is tagged granules (ar_granules.hpp).  All weights of
+// a launch are requested at its start, so the in-launch stages pay a hop and their arithmetic, not a memory latency.  Placement
+// (blockIdx % 8 == XCD) is a speed assumption only: the granules are written through (sc1) and polled with sc1 loads, valid
+// across XCDs.
 // Reference arithmetic: valle/modules/transformer.py:297-334 (pre-norm encoder layer), activation.py:407-427.
 #pragma once
 #include <type_traits>
@@ -57,7 +59,7 @@ struct TpAccArgs {
 };
 constexpr float TP_FIX = 4294967296.0f, TP_UNFIX = 2.3283064365386963e-10f;
 __device__ __forceinline__ long long tp_fix(float v) { return __float2ll_rn(v * TP_FIX); }
-// The LayerNorm affine and the bias that arrives with the partials travel as ONE (3, 1024) block {gamma, beta, bias} per norm
+// The LayerNorm affine travels as ONE (3, 1024) block {gamma, beta, (unused: the bias is added by the producer)} per norm
 // site (packed at vx_finalize_weights), so that a single preloaded pointer reaches them: their loads go out with the row's,
 // in front of the weight stream (vmcnt retires in order - behind the weights the norm would wait for the whole stream).
 
