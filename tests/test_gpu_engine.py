@@ -121,6 +121,39 @@ def test_sharded_step_matches_plain_step_beyond_one_key_pass(monkeypatch):
     assert bool((a.argmax(1) == b.argmax(1))[decided].all())
 
 
+def test_sharded_step_does_not_depend_on_uninitialised_memory():
+    """VX_POISON=1 fills every fresh device allocation (including the slices of the small-block arena) with 0xFF bytes before the
+    engine initialises it: the XCD-sharded decode step's granule scratch, accumulators and re-laid-out weights must all be written
+    before they are read - same codes with and without the poison (d = 1024 / 16 heads / 2 layers, bf16, graph replay)."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    script = (
+        "import sys, json, torch; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge; ge.build()\n"
+        "from valle_amd.config import ModelConfig\n"
+        "from valle_amd.models import VALLE\n"
+        "from valle_amd.weights import synthetic_inputs, synthetic_state_dict\n"
+        "cfg = ModelConfig(decoder_dim=1024, nhead=16, num_decoder_layers=2, prefix_mode=1)\n"
+        "m = VALLE(1024, 16, 2, prefix_mode=1, precision='bf16', max_text=32, max_audio=256, print_eos=False)\n"
+        "m.load_state_dict(synthetic_state_dict(cfg, 3)); m.to('cuda:0').eval()\n"
+        "x, xl, y = synthetic_inputs(5, 40, 8, seed=2)\n"
+        "out = []\n"
+        "for seed in (1, 2):\n"
+        "    torch.manual_seed(seed); out.append(m.inference(x.cuda(), xl.cuda(), y.cuda(), None, top_k=5).flatten().tolist())\n"
+        "print(json.dumps(out))\n" % ROOT)
+    outs = []
+    for poison in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, VX_POISON=poison), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
+    assert all(len(seq) == 81 * 8 and all(0 <= v < 1024 for v in seq) for seq in outs[0])
+
+
 def test_graph_and_eager_steps_agree():
     g = Golden("cfg0_topk10")
     a = _run(_model(g, "fp32"), g)
