@@ -275,7 +275,9 @@ __global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ W
     vb = reinterpret_cast<const WT*>(vcp) + (size_t)h * ctxm * HD + sub * VEC;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const int jk = min(j0 + u * KPB + wave * KPW + grp, max(n_old, 1) - 1);  // clamped: row 0 always exists
+      // slots past the split's end re-read the split's OWN last key (row 0 always exists): clamped to the context's last row they
+      // were one more line every workgroup of the head asked for at the same moment
+      const int jk = min(j0 + u * KPB + wave * KPW + grp, max(j1, 1) - 1);
       tp_ld16(kr[u], kb + (size_t)jk * HD);
       tp_ld16(vr[u], vb + (size_t)jk * HD);
     }
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(256) void tp_attn_kernel(const void* __restrict__ W
   auto load_pass = [&](int base) {  // later passes of a long context (> 16 * UNR * KPB rows): plain loads
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const int jk = min(base + u * KPB + wave * KPW + grp, max(n_old, 1) - 1);
+      const int jk = min(base + u * KPB + wave * KPW + grp, max(j1, 1) - 1);
       const uint4 k4 = ld16(kb + (size_t)jk * HD), v4 = ld16(vb + (size_t)jk * HD);
       kr[u] = vx_u32x4{k4.x, k4.y, k4.z, k4.w};
       vr[u] = vx_u32x4{v4.x, v4.y, v4.z, v4.w};
