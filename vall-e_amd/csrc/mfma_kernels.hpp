@@ -37,16 +37,31 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
   // K = the K range this workgroup multiplies, ld = row stride of A and W.  gridDim.z > 1: split K across
   // workgroups, slice z covers columns [z K, (z+1) K) and writes its own (M, N) fp32 slab (GE_PLAIN, OUT_F32): the
   // LayerNorm that follows the GEMM anyway adds bias + slabs in a fixed order (deterministic, no atomics).
-  A += (size_t)blockIdx.z * K;
-  W += (size_t)blockIdx.z * K;
-  if (OUT_F32) Cv = reinterpret_cast<float*>(Cv) + (size_t)blockIdx.z * M * N;
+  // Which tile: launch slot lin = x + gx (y + gy z) runs on XCD lin % 8.  With gx % 8 == 0 (QKV, FFN1) an N tile's M tiles already
+  // share an XCD.  The split-K launches of the N = d GEMMs (gx = 8, gz slices) put an N tile's slices AND all M tiles on one
+  // XCD: per 64 of k it then pulls gy gz A tiles + gz W tiles over the fabric (FFN2 at 1025 rows: 20 tiles = 320 KB per XCD and
+  // step, 5.9 TB/s chip-wide at the measured 0.43 us per step).  VX_GEMM_XCD_Z (A/B): XCD x takes slice x % gz of the N tiles
+  // [(x / gz) gz, +gz) instead - gy A tiles + gz W tiles (11 tiles = 176 KB).  Speed only: a bijection of the grid.
+  int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+#ifdef VX_GEMM_XCD_Z
+  if (gridDim.z > 1 && gridDim.x == 8) {
+    const int gy = gridDim.y, gz = gridDim.z;
+    const int lin = blockIdx.x + 8 * (blockIdx.y + gy * blockIdx.z), xcd = lin & 7, idx = lin >> 3;  // idx < gy gz
+    bzi = xcd % gz;
+    bxi = (xcd / gz) * gz + idx / gy;
+    byi = idx % gy;
+  }
+#endif
+  A += (size_t)bzi * K;
+  W += (size_t)bzi * K;
+  if (OUT_F32) Cv = reinterpret_cast<float*>(Cv) + (size_t)bzi * M * N;
   constexpr int BM = 128, BN = 128, BK = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // layout: [buf][A|W][128 rows * 128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = byi * BM, n0 = bxi * BN;
 
   f32x16_t acc[2][2];
 #pragma unroll
@@ -1290,13 +1305,29 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
                                                                  const int* __restrict__ seg_len,
                                                                  const int* __restrict__ seg_text) {
   constexpr int HD = 64, NT = NW * KG * 64;
+  // XCD-aware placement: workgroups are handed to the 8 XCDs round-robin in launch order, so the query blocks of one
+  // (head, segment) - which all stream the SAME K / V^T rows - would land on 8 different L2s and each fetch them over the fabric
+  // (32 x 1088 rows: 1.28 GB per layer-stage for 142 MB of distinct K / V; 6 TB/s of fabric reads at the measured 211 us).
+  // Launch slot `lin` therefore works on logical block (lin % 8) * (total / 8) + lin / 8: every XCD gets a CONTIGUOUS run of
+  // logical blocks (query block fastest), i.e. all query blocks of a (head, segment) share one L2 and run back to back.
+  // Speed only - any mapping is a bijection of the grid.
+  int bx, by, bz;
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned n8 = total >> 3;
+    const unsigned logical = lin < (n8 << 3) ? (lin & 7u) * n8 + (lin >> 3) : lin;
+    bx = (int)(logical % gx);
+    by = (int)((logical / gx) % gy);
+    bz = (int)(logical / (gx * gy));
+  }
   // batched NAR / prefill: segment z of a concatenated row buffer (starts are multiples of 64 rows, so the 16-byte
   // K / V^T tile loads stay aligned); single sequence: seg_start == nullptr
   if (seg_start != nullptr) {
-    const int r0 = seg_start[blockIdx.z];
-    M = seg_len[blockIdx.z];
-    if (seg_text != nullptr) text_len = seg_text[blockIdx.z];  // batched prefill: every utterance has its own text length
-    if ((int)blockIdx.x * 32 * NW >= M) return;
+    const int r0 = seg_start[bz];
+    M = seg_len[bz];
+    if (seg_text != nullptr) text_len = seg_text[bz];  // batched prefill: every utterance has its own text length
+    if (bx * 32 * NW >= M) return;
     qkv += (size_t)r0 * 3 * d;
     out += (size_t)r0 * d;
     vt += r0;
@@ -1307,8 +1338,8 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qw = wave % NW, kg = wave / NW;
   const int r = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y;
-  const int q0 = blockIdx.x * (32 * NW) + qw * 32;
+  const int head = by;
+  const int q0 = bx * (32 * NW) + qw * 32;
   const int ld3 = 3 * d;
   const int qrow = q0 + r;
   const bool qvalid = qrow < M;
@@ -1328,7 +1359,7 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
   const int limit = !qvalid ? 0 : (text_len < 0 ? M : (qrow < text_len ? text_len : qrow + 1));
   int blk_limit = M;  // highest key any query of the workgroup may see
   if (text_len >= 0) {
-    const int last = min(M, (int)(blockIdx.x + 1) * 32 * NW) - 1;
+    const int last = min(M, (bx + 1) * 32 * NW) - 1;
     blk_limit = last < text_len ? text_len : last + 1;
   }
   const int ntiles = (blk_limit + 63) / 64;
@@ -1356,9 +1387,15 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       const int q = tid + i * NT, g = q >> 9, row = (q >> 3) & 63, c = q & 7;
-      const int off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
-      *reinterpret_cast<uint4*>(ldsp(buf, g, 0) + off) = R.k[i];
-      *reinterpret_cast<uint4*>(ldsp(buf, g, 1) + off) = R.v[i];
+      const int sw = (row >> 1) & 7;
+      *reinterpret_cast<uint4*>(ldsp(buf, g, 0) + row * 128 + ((c ^ sw) << 4)) = R.k[i];
+      // V^T: the second product's A fragment of half-wave hh is keys {4hh..4hh+3} and {8+4hh..8+4hh+3} of a 16-key group
+      // (the accumulator order of S^T, see below), so the group's two 8-key chunks are regrouped on the way in - chunk 2g holds
+      // keys {0-3, 8-11}, chunk 2g+1 keys {4-7, 12-15} - and a fragment is ONE 16-byte read (two 8-byte reads plus three register
+      // moves per fragment before: 24 of the loop's ~190 VALU instructions)
+      unsigned char* vrow_p = ldsp(buf, g, 1) + row * 128 + 8 * (c & 1);
+      *reinterpret_cast<uint2*>(vrow_p + (((c & 6) ^ sw) << 4)) = make_uint2(R.v[i].x, R.v[i].y);
+      *reinterpret_cast<uint2*>(vrow_p + (((c | 1) ^ sw) << 4)) = make_uint2(R.v[i].z, R.v[i].w);
     }
   };
 
@@ -1376,7 +1413,8 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
   __syncthreads();
   VX_STAMP(9);
   // iteration `it`: tile set it+2 -> RL (the set tile it left), multiply LDS buffer it & 1, tile set it+1 (in RS) -> the other buffer
-  auto step = [&](int it, TileRegs& RL, const TileRegs& RS) {
+  auto step = [&](auto masked_c, int it, TileRegs& RL, const TileRegs& RS) {
+    constexpr bool MASKED = decltype(masked_c)::value;
     const int cur = it & 1, kt = (it * KG + kg) * 64;
 #ifdef VX_STAMPS
     if (it < 12) VX_STAMP(10 + it);
@@ -1385,99 +1423,120 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
     else if (it + 1 < niter) gload(RL, it + 1);
     const unsigned char* kb = ldsp(cur, kg, 0);
     const unsigned char* vb = ldsp(cur, kg, 1);
-    // S^T for the two 32-key sub-tiles
+    // S^T for the two 32-key sub-tiles.  All eight K fragments are requested before the first product (left alone the compiler
+    // read every fragment into the same four registers: read, wait, multiply, eight times over)
+    const int swz = (r >> 1) & 7;  // rows r and r + 32 swizzle alike
+    bf16x8_t kf[2][4];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        kf[sub][ks] = *reinterpret_cast<const bf16x8_t*>(kb + (sub * 32 + r) * 128 + (((ks * 2 + hh) ^ swz) << 4));
     f32x16_t accS[2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) accS[sub][v] = 0.f;
-      const int krow = sub * 32 + r;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + krow * 128 + (((ks * 2 + hh) ^ ((krow >> 1) & 7)) << 4));
-        accS[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], accS[sub], 0, 0, 0);
-      }
+      for (int ks = 0; ks < 4; ++ks) accS[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][ks], qf[ks], accS[sub], 0, 0, 0);
     }
-    // mask + running max (register v of half hh holds key (v&3) + 8(v>>2) + 4hh of the sub-tile).  A tile every
-    // query of the wave sees in full needs no per-element mask (wave-uniform test): all but the last tile of an
-    // unmasked (NAR) stage, and every tile left of the diagonal under the prefix mask.
-    float mloc = -INFINITY;
-    if (__builtin_amdgcn_ballot_w64(kt + 64 > limit) == 0) {
+    if (!TWO) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // 8 LDS reads
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // 8 MFMAs
+    } else {  // two register sets of tile loads are live here: four fragments ahead instead of eight (eight spilled)
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) mloc = fmaxf(mloc, accS[sub][v]);
-    } else {
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    // Per-element masking exists only in the MASKED instance of this body (register v of half hh holds key
+    // (v&3) + 8(v>>2) + 4hh of the sub-tile): the tile loop below runs the plain instance over the tiles EVERY query of the
+    // workgroup sees in full - all but the last tile of an unmasked (NAR) stage, everything left of the diagonal under the prefix
+    // mask - and the masked one over the rest.  One body with a wave-uniform choice per tile cost the plain path 16 64-bit
+    // register moves per tile (S^T or O^T copied to where the other path keeps it).
+    {
+      float mloc = -INFINITY;
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          const int kgi = kt + sub * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
-          const float sv = (kgi < limit) ? accS[sub][v] : -INFINITY;
-          accS[sub][v] = sv;
-          mloc = fmaxf(mloc, sv);
+          if (MASKED) {
+            const int kgi = kt + sub * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
+            accS[sub][v] = (kgi < limit) ? accS[sub][v] : -INFINITY;
+          }
+          mloc = fmaxf(mloc, accS[sub][v]);
         }
-    }
-    mloc = fmaxf(mloc, xor32_f(mloc));
-    const float m_new = fmaxf(m_run, mloc);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: exp(-inf - 0) = 0
-    // rescale the running sums only when some query's maximum moved (wave-uniform test; the factor is exactly 1
-    // otherwise): after the first few key tiles it rarely does
-    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
-      const float corr = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_use) * 1.4426950408889634f);
-      l_run *= corr;
+      mloc = fmaxf(mloc, xor32_f(mloc));
+      const float m_new = fmaxf(m_run, mloc);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: exp(-inf - 0) = 0
+      // rescale the running sums only when some query's maximum moved (wave-uniform test; the factor is exactly 1
+      // otherwise): after the first few key tiles it rarely does
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+        const float corr = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_use) * 1.4426950408889634f);
+        l_run *= corr;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) accO[t][v] *= corr;
-    }
-    m_run = m_new;
-    // P^T = exp(S^T - m) = exp2(S^T log2(e) - m log2(e)): one fma + v_exp_f32 per element (the exp's own range scaling and the
-    // separate multiply were 2 of the ~9 VALU slots per element of this loop, which is VALU-bound: 16 MFMAs against ~280 slots);
-    // row sums on packed adds; cast to bf16 in accumulator order = B fragments of the next product
-    constexpr float LOG2E = 1.4426950408889634f;
-    const float m2 = m_use * LOG2E;
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    f32x2_t l2 = {0.f, 0.f};
-    bf16x8_t pf[2][2];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int v = 0; v < 16; v += 2) {
-        f32x2_t p2;
-        p2.x = __builtin_amdgcn_exp2f(fmaf(accS[sub][v], LOG2E, -m2));
-        p2.y = __builtin_amdgcn_exp2f(fmaf(accS[sub][v + 1], LOG2E, -m2));
-        l2 += p2;
-        pf[sub][v >> 3][v & 7] = (bf16)p2.x;
-        pf[sub][v >> 3][(v & 7) + 1] = (bf16)p2.y;
+          for (int v = 0; v < 16; ++v) accO[t][v] *= corr;
       }
-    l_run += l2.x + l2.y;
-    // O^T += V^T . P^T : element j of half hh is key 16s + 8(j>>2) + 4hh + (j&3) of the sub-tile
+      m_run = m_new;
+      // P^T = exp(S^T - m) = exp2(S^T log2(e) - m log2(e)): one fma + v_exp_f32 per element; row sums on packed adds in two
+      // independent chains (one chain was an add + a wait state per pair); cast to bf16 in accumulator order = B fragments of
+      // the next product
+      constexpr float LOG2E = 1.4426950408889634f;
+      const float m2 = m_use * LOG2E;
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      f32x2_t l2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+      bf16x8_t pf[2][2];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+      for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int c0 = sub * 4 + s2 * 2;  // 16-byte chunk of keys [sub*32 + 16*s2, +8); the second half is chunk c0+1
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int vrow = t * 32 + r;
-          const unsigned char* rowp = vb + vrow * 128 + 8 * hh;
-          union { bf16x8_t v8; uint2 u[2]; } vf;
-          vf.u[0] = *reinterpret_cast<const uint2*>(rowp + ((c0 ^ ((vrow >> 1) & 7)) << 4));
-          vf.u[1] = *reinterpret_cast<const uint2*>(rowp + (((c0 + 1) ^ ((vrow >> 1) & 7)) << 4));
-          accO[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v8, pf[sub][s2], accO[t], 0, 0, 0);
+        for (int v = 0; v < 16; v += 2) {
+          f32x2_t p2;
+          p2.x = __builtin_amdgcn_exp2f(fmaf(accS[sub][v], LOG2E, -m2));
+          p2.y = __builtin_amdgcn_exp2f(fmaf(accS[sub][v + 1], LOG2E, -m2));
+          l2[(v >> 1) & 1] += p2;
+          pf[sub][v >> 3][v & 7] = (bf16)p2.x;
+          pf[sub][v >> 3][(v & 7) + 1] = (bf16)p2.y;
         }
-      }
+      l_run += (l2[0].x + l2[1].x) + (l2[0].y + l2[1].y);
+      // O^T += V^T . P^T : element j of half hh is key 16 s2 + 8(j>>2) + 4hh + (j&3) of the sub-tile = chunk 2(2 sub + s2) + hh
+      // of the regrouped V^T row
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + (t * 32 + r) * 128 + (((2 * (2 * sub + s2) + hh) ^ swz) << 4));
+            accO[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][s2], accO[t], 0, 0, 0);
+          }
+    }
     if (it + 1 < niter) lstore(RS, cur ^ 1);
     __syncthreads();
   };
+  // iterations whose tiles every valid query of the workgroup sees in full (a query row past M is never stored: it may see anything)
+  const int wg_row0 = bx * 32 * NW;
+  const int min_limit = text_len < 0 ? M : (wg_row0 < text_len ? text_len : wg_row0 + 1);
+  const int n_plain = min(niter, (min_limit / 64) / KG);
+  constexpr std::false_type PLAIN{};
+  constexpr std::true_type MASK{};
+  int it = 0;
   if (TWO) {
-    for (int it = 0; it < niter; it += 2) {
-      step(it, R0, R1);
-      if (it + 1 < niter) step(it + 1, R1, R0);
+    for (; it + 1 < n_plain; it += 2) {
+      step(PLAIN, it, R0, R1);
+      step(PLAIN, it + 1, R1, R0);
+    }
+    for (; it < niter; it += 2) {  // `it` is even here
+      step(MASK, it, R0, R1);
+      if (it + 1 < niter) step(MASK, it + 1, R1, R0);
     }
   } else {
-    for (int it = 0; it < niter; ++it) step(it, R0, R0);
+    for (; it < n_plain; ++it) step(PLAIN, it, R0, R0);
+    for (; it < niter; ++it) step(MASK, it, R0, R0);
   }
   VX_STAMP(22);
   float l_tot = l_run + xor32_f(l_run);
