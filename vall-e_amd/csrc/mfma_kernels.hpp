@@ -37,7 +37,21 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(const bf16* __restrict__
   // K = the K range this workgroup multiplies, ld = row stride of A and W.  gridDim.z > 1: split K across
   // workgroups, slice z covers columns [z K, (z+1) K) and writes its own (M, N) fp32 slab (GE_PLAIN, OUT_F32): the
   // LayerNorm that follows the GEMM anyway adds bias + slabs in a fixed order (deterministic, no atomics).
-  const int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+  // Which tile: launch slot lin = x + gx (y + gy z) runs on XCD lin % 8.  With gx % 8 == 0 (QKV, FFN1) an N tile's M tiles already
+  // share an XCD.  The split-K launches of the N = d GEMMs (gx = 8, gz slices) put an N tile's slices AND all M tiles on one
+  // XCD: per 64 of k it then pulls gy gz A tiles + gz W tiles over the fabric (FFN2 at 1025 rows: 20 tiles = 320 KB per XCD and
+  // step, 5.9 TB/s chip-wide at the measured 0.43 us per step).  VX_GEMM_XCD_Z (A/B): XCD x takes slice x % gz of the N tiles
+  // [(x / gz) gz, +gz) instead - gy A tiles + gz W tiles (11 tiles = 176 KB).  Speed only: a bijection of the grid.
+  int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+#ifdef VX_GEMM_XCD_Z
+  if (gridDim.z > 1 && gridDim.x == 8) {
+    const int gy = gridDim.y, gz = gridDim.z;
+    const int lin = blockIdx.x + 8 * (blockIdx.y + gy * blockIdx.z), xcd = lin & 7, idx = lin >> 3;  // idx < gy gz
+    bzi = xcd % gz;
+    bxi = (xcd / gz) * gz + idx / gy;
+    byi = idx % gy;
+  }
+#endif
   A += (size_t)bzi * K;
   W += (size_t)bzi * K;
   if (OUT_F32) Cv = reinterpret_cast<float*>(Cv) + (size_t)bzi * M * N;
@@ -1391,38 +1405,44 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
 #pragma unroll
     for (int v = 0; v < 16; ++v) accO[t][v] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;  // l_run: this half-wave's share of the row sum
-  const int swz = (r >> 1) & 7;  // LDS rows r and r + 32 swizzle alike
 
-  // S^T = K . Q^T for the two 32-key sub-tiles of one staged tile.  All K fragments are requested before the first product (left
-  // alone the compiler read every fragment into the same four registers: read, wait, multiply, eight times over).  PIPE (the
-  // software-pipelined loop below): the eight products are spread over the VALU work that follows them in program order - a wave
-  // issues in order, so a dependent MFMA stalls everything behind it unless independent instructions sit between the products.
-  auto s_phase = [&](const unsigned char* kb, f32x16_t (&S)[2], auto pipe_c) {
-    constexpr bool PIPE = decltype(pipe_c)::value;
+  VX_STAMP(8);
+  gload(R0, 0);
+  lstore(R0, 0);
+  if (TWO) gload(R1, min(1, niter - 1));
+  __syncthreads();
+  VX_STAMP(9);
+  // iteration `it`: tile set it+2 -> RL (the set tile it left), multiply LDS buffer it & 1, tile set it+1 (in RS) -> the other buffer
+  auto step = [&](auto masked_c, int it, TileRegs& RL, const TileRegs& RS) {
+    constexpr bool MASKED = decltype(masked_c)::value;
+    const int cur = it & 1, kt = (it * KG + kg) * 64;
+#ifdef VX_STAMPS
+    if (it < 12) VX_STAMP(10 + it);
+#endif
+    if (TWO) gload(RL, min(it + 2, niter - 1));
+    else if (it + 1 < niter) gload(RL, it + 1);
+    const unsigned char* kb = ldsp(cur, kg, 0);
+    const unsigned char* vb = ldsp(cur, kg, 1);
+    // S^T for the two 32-key sub-tiles.  All eight K fragments are requested before the first product (left alone the compiler
+    // read every fragment into the same four registers: read, wait, multiply, eight times over)
+    const int swz = (r >> 1) & 7;  // rows r and r + 32 swizzle alike
     bf16x8_t kf[2][4];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
         kf[sub][ks] = *reinterpret_cast<const bf16x8_t*>(kb + (sub * 32 + r) * 128 + (((ks * 2 + hh) ^ swz) << 4));
+    f32x16_t accS[2];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) S[sub][v] = 0.f;
+      for (int v = 0; v < 16; ++v) accS[sub][v] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) S[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][ks], qf[ks], S[sub], 0, 0, 0);
-    if (PIPE) {
+      for (int ks = 0; ks < 4; ++ks) accS[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][ks], qf[ks], accS[sub], 0, 0, 0);
+    }
+    if (!TWO) {
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // 8 LDS reads
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one product ...
-        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);  // ... seven VALU instructions of the softmax (its matrix time) behind it
-      }
-    } else if (!TWO) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // 8 MFMAs
     } else {  // two register sets of tile loads are live here: four fragments ahead instead of eight (eight spilled)
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
@@ -1432,75 +1452,73 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
-  };
-  // Online softmax of one tile's S^T and O^T += V^T . P^T.  Per-element masking exists only in the MASKED instance (register v of
-  // half hh holds key (v&3) + 8(v>>2) + 4hh of the sub-tile): the tile loops below run the plain instance over the tiles EVERY
-  // query of the workgroup sees in full - all but the last tile of an unmasked (NAR) stage, everything left of the diagonal under
-  // the prefix mask - and the masked one over the rest.  One body with a wave-uniform choice per tile cost the plain path 16
-  // 64-bit register moves per tile (S^T or O^T copied to where the other path keeps it).
-  // `mid()` runs behind the (rare, wave-uniform) rescale branch: the pipelined loop puts the NEXT tile's products there, in one
-  // basic block with the exponentials they are to run under.
-  auto softmax_pv = [&](auto masked_c, int kt, const unsigned char* vb, f32x16_t (&accS)[2], auto&& mid) {
-    constexpr bool MASKED = decltype(masked_c)::value;
-    float mloc = -INFINITY;
+    // Per-element masking exists only in the MASKED instance of this body (register v of half hh holds key
+    // (v&3) + 8(v>>2) + 4hh of the sub-tile): the tile loop below runs the plain instance over the tiles EVERY query of the
+    // workgroup sees in full - all but the last tile of an unmasked (NAR) stage, everything left of the diagonal under the prefix
+    // mask - and the masked one over the rest.  One body with a wave-uniform choice per tile cost the plain path 16 64-bit
+    // register moves per tile (S^T or O^T copied to where the other path keeps it).
+    {
+      float mloc = -INFINITY;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+      for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        if (MASKED) {
-          const int kgi = kt + sub * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
-          accS[sub][v] = (kgi < limit) ? accS[sub][v] : -INFINITY;
+        for (int v = 0; v < 16; ++v) {
+          if (MASKED) {
+            const int kgi = kt + sub * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
+            accS[sub][v] = (kgi < limit) ? accS[sub][v] : -INFINITY;
+          }
+          mloc = fmaxf(mloc, accS[sub][v]);
         }
-        mloc = fmaxf(mloc, accS[sub][v]);
+      mloc = fmaxf(mloc, xor32_f(mloc));
+      const float m_new = fmaxf(m_run, mloc);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: exp(-inf - 0) = 0
+      // rescale the running sums only when some query's maximum moved (wave-uniform test; the factor is exactly 1
+      // otherwise): after the first few key tiles it rarely does
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+        const float corr = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_use) * 1.4426950408889634f);
+        l_run *= corr;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) accO[t][v] *= corr;
       }
-    mloc = fmaxf(mloc, xor32_f(mloc));
-    const float m_new = fmaxf(m_run, mloc);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: exp(-inf - 0) = 0
-    // rescale the running sums only when some query's maximum moved (wave-uniform test; the factor is exactly 1
-    // otherwise): after the first few key tiles it rarely does
-    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
-      const float corr = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_use) * 1.4426950408889634f);
-      l_run *= corr;
+      m_run = m_new;
+      // P^T = exp(S^T - m) = exp2(S^T log2(e) - m log2(e)): one (packed) fma + v_exp_f32 per element; row sums on packed adds in two
+      // independent chains (one chain was an add + a wait state per pair); cast to bf16 in accumulator order = B fragments of
+      // the next product
+      constexpr float LOG2E = 1.4426950408889634f;
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      const f32x2_t le2 = {LOG2E, LOG2E}, nm2 = {-m_use * LOG2E, -m_use * LOG2E};
+      f32x2_t l2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+      bf16x8_t pf[2][2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) accO[t][v] *= corr;
+        for (int v = 0; v < 16; v += 2) {
+          const f32x2_t s2 = {accS[sub][v], accS[sub][v + 1]};
+          const f32x2_t e2 = __builtin_elementwise_fma(s2, le2, nm2);  // v_pk_fma_f32: two elements per instruction
+          f32x2_t p2;
+          p2.x = __builtin_amdgcn_exp2f(e2.x);
+          p2.y = __builtin_amdgcn_exp2f(e2.y);
+          l2[(v >> 1) & 1] += p2;
+          pf[sub][v >> 3][v & 7] = (bf16)p2.x;
+          pf[sub][v >> 3][(v & 7) + 1] = (bf16)p2.y;
+        }
+      l_run += (l2[0].x + l2[1].x) + (l2[0].y + l2[1].y);
+      // O^T += V^T . P^T : element j of half hh is key 16 s2 + 8(j>>2) + 4hh + (j&3) of the sub-tile = chunk 2(2 sub + s2) + hh
+      // of the regrouped V^T row
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + (t * 32 + r) * 128 + (((2 * (2 * sub + s2) + hh) ^ swz) << 4));
+            accO[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][s2], accO[t], 0, 0, 0);
+          }
     }
-    m_run = m_new;
-    mid();
-    // P^T = exp(S^T - m) = exp2(S^T log2(e) - m log2(e)): one (packed) fma + v_exp_f32 per element; row sums on packed adds in
-    // two independent chains (one chain was an add + a wait state per pair); cast to bf16 in accumulator order = B fragments of
-    // the next product
-    constexpr float LOG2E = 1.4426950408889634f;
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    const f32x2_t le2 = {LOG2E, LOG2E}, nm2 = {-m_use * LOG2E, -m_use * LOG2E};
-    f32x2_t l2[2] = {{0.f, 0.f}, {0.f, 0.f}};
-    bf16x8_t pf[2][2];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int v = 0; v < 16; v += 2) {
-        const f32x2_t s2 = {accS[sub][v], accS[sub][v + 1]};
-        const f32x2_t e2 = __builtin_elementwise_fma(s2, le2, nm2);
-        f32x2_t p2;
-        p2.x = __builtin_amdgcn_exp2f(e2.x);
-        p2.y = __builtin_amdgcn_exp2f(e2.y);
-        l2[(v >> 1) & 1] += p2;
-        pf[sub][v >> 3][v & 7] = (bf16)p2.x;
-        pf[sub][v >> 3][(v & 7) + 1] = (bf16)p2.y;
-      }
-    l_run += (l2[0].x + l2[1].x) + (l2[0].y + l2[1].y);
-    // O^T += V^T . P^T : element j of half hh is key 16 s2 + 8(j>>2) + 4hh + (j&3) of the sub-tile = chunk 2(2 sub + s2) + hh
-    // of the regrouped V^T row
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + (t * 32 + r) * 128 + (((2 * (2 * sub + s2) + hh) ^ swz) << 4));
-          accO[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][s2], accO[t], 0, 0, 0);
-        }
+    if (it + 1 < niter) lstore(RS, cur ^ 1);
+    __syncthreads();
   };
   // iterations whose tiles every valid query of the workgroup sees in full (a query row past M is never stored: it may see anything)
   const int wg_row0 = bx * 32 * NW;
@@ -1508,28 +1526,8 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
   const int n_plain = min(niter, (min_limit / 64) / KG);
   constexpr std::false_type PLAIN{};
   constexpr std::true_type MASK{};
-
-  VX_STAMP(8);
-  if constexpr (TWO) {
-    gload(R0, 0);
-    lstore(R0, 0);
-    gload(R1, min(1, niter - 1));
-    __syncthreads();
-    VX_STAMP(9);
-    // iteration `it`: tile set it+2 -> RL (the set tile it left), multiply LDS buffer it & 1, tile set it+1 (in RS) -> the other buffer
-    auto step = [&](auto masked_c, int it, TileRegs& RL, const TileRegs& RS) {
-      const int cur = it & 1, kt = (it * KG + kg) * 64;
-#ifdef VX_STAMPS
-      if (it < 12) VX_STAMP(10 + it);
-#endif
-      gload(RL, min(it + 2, niter - 1));
-      f32x16_t accS[2];
-      s_phase(ldsp(cur, kg, 0), accS, std::false_type{});
-      softmax_pv(masked_c, kt, ldsp(cur, kg, 1), accS, [] {});
-      if (it + 1 < niter) lstore(RS, cur ^ 1);
-      __syncthreads();
-    };
-    int it = 0;
+  int it = 0;
+  if (TWO) {
     for (; it + 1 < n_plain; it += 2) {
       step(PLAIN, it, R0, R1);
       step(PLAIN, it + 1, R1, R0);
@@ -1539,41 +1537,8 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
       if (it + 1 < niter) step(MASK, it + 1, R1, R0);
     }
   } else {
-    // Software-pipelined loop (many workgroups per CU: batched NAR / prefill): S^T of tile it+1 is multiplied WHILE tile it goes
-    // through its softmax, so the matrix pipe works under the VALU instructions instead of in front of them - rocprofv3 counters of
-    // the one-tile-at-a-time loop at 32 x 1088 rows: VALU busy 65 % + matrix pipe busy 34 % of the SIMD cycles, i.e. nothing overlapped
-    // (profiles/r03_pmc_nar_batch32.json).  Three LDS slots (tile t in slot t % 3): iteration `it` reads K of it+1 and V^T of it and
-    // writes tile it+2 (requested one iteration ago) into the slot tile it-1 left at the last barrier.  Loads and stores are
-    // unconditional on clamped tile indices; the product past the last tile is computed and dropped.
-    auto slot_k = [&](int t) { return ldsp(t % 3, 0, 0); };
-    auto slot_v = [&](int t) { return ldsp(t % 3, 0, 1); };
-    gload(R0, 0);
-    lstore(R0, 0);
-    gload(R0, min(1, niter - 1));
-    lstore(R0, 1);
-    gload(R0, min(2, niter - 1));
-    __syncthreads();
-    VX_STAMP(9);
-    f32x16_t S0[2], S1[2];
-    s_phase(slot_k(0), S0, std::false_type{});
-    auto pstep = [&](auto masked_c, int it, f32x16_t (&Sc)[2], f32x16_t (&Sn)[2]) {
-#ifdef VX_STAMPS
-      if (it < 12) VX_STAMP(10 + it);
-#endif
-      lstore(R0, (it + 2) % 3);
-      gload(R0, min(it + 3, niter - 1));
-      softmax_pv(masked_c, it * 64, slot_v(it), Sc, [&] { s_phase(slot_k(it + 1), Sn, std::true_type{}); });
-      __syncthreads();
-    };
-    int it = 0;
-    for (; it + 1 < n_plain; it += 2) {
-      pstep(PLAIN, it, S0, S1);
-      pstep(PLAIN, it + 1, S1, S0);
-    }
-    for (; it < niter; it += 2) {  // `it` is even here
-      pstep(MASK, it, S0, S1);
-      if (it + 1 < niter) pstep(MASK, it + 1, S1, S0);
-    }
+    for (; it < n_plain; ++it) step(PLAIN, it, R0, R0);
+    for (; it < niter; ++it) step(MASK, it, R0, R0);
   }
   VX_STAMP(22);
   float l_tot = l_run + xor32_f(l_run);
@@ -1653,9 +1618,9 @@ static inline int mfma_attn_dispatch(const bf16* qkv, const bf16* vt, int vt_ld,
   else if (kg == 2)
     mfma_attn_kernel<2, 2><<<grid, 2 * 2 * 64, 65536, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
   else if (nw == 4)
-    mfma_attn_kernel<4, 1><<<grid, 4 * 64, 49152, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
+    mfma_attn_kernel<4, 1><<<grid, 4 * 64, 32768, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
   else
-    mfma_attn_kernel<2, 1><<<grid, 2 * 64, 49152, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
+    mfma_attn_kernel<2, 1><<<grid, 2 * 64, 32768, s>>>(qkv, vt, out, M, vt_ld, d, text_len, seg_start, seg_len, seg_text);
   return 0;
 }
 
