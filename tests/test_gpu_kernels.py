@@ -156,29 +156,40 @@ def test_mfma_gemm_layout_asymmetric(eng):
 
 
 def _attn_ref(qkv, H, text_len):
+    """fp64 SDPA with the reference's prefix mask (valle.py:1019-1033), on the qkv tensor's device, 16 heads at a time."""
     N, d3 = qkv.shape
     d = d3 // 3
     q, k, v = qkv.double().chunk(3, -1)
     sp = lambda t: t.reshape(N, H, d // H).transpose(0, 1)
-    s = sp(q) @ sp(k).transpose(1, 2) / (d // H) ** 0.5
+    m = None
     if text_len >= 0:
-        m = torch.zeros(N, N, dtype=torch.bool)
+        m = torch.zeros(N, N, dtype=torch.bool, device=qkv.device)
         m[:text_len, text_len:] = True
         A = N - text_len
-        m[text_len:, text_len:] = torch.triu(torch.ones(A, A, dtype=torch.bool), 1)
-        s = s.masked_fill(m, float("-inf"))
-    return (torch.softmax(s, -1) @ sp(v)).transpose(0, 1).reshape(N, d).float()
+        m[text_len:, text_len:] = torch.triu(torch.ones(A, A, dtype=torch.bool, device=qkv.device), 1)
+    outs = []
+    for h0 in range(0, H, 16):
+        s = sp(q)[h0 : h0 + 16] @ sp(k)[h0 : h0 + 16].transpose(1, 2) / (d // H) ** 0.5
+        if m is not None:
+            s = s.masked_fill(m, float("-inf"))
+        outs.append(torch.softmax(s, -1) @ sp(v)[h0 : h0 + 16])
+    return torch.cat(outs).transpose(0, 1).reshape(N, d).float()
 
 
-@pytest.mark.parametrize("N,H,text_len", [(272, 16, 47), (1025, 16, -1), (70, 4, 10), (63, 2, -1), (130, 4, 0), (9, 2, 9)])
+# (1800, 16, *): configs[4]'s segment length on the two-key-group kernel; (1100, 128, *): 18 x 128 = 2304 (query block, head) pairs
+# put the stand-alone op on the four-query-wave kernel of the batched stages (plain + masked tile loops, XCD-aware block order)
+@pytest.mark.parametrize("N,H,text_len", [(272, 16, 47), (1025, 16, -1), (70, 4, 10), (63, 2, -1), (130, 4, 0), (9, 2, 9),
+                                          (1800, 16, -1), (1800, 16, 94), (1100, 128, -1), (1100, 128, 94), (1100, 128, 1100)])
 def test_attention_rows(eng, N, H, text_len):
+    big = N * H > 20000  # reference on the GPU (plain torch fp64), the fp32 scalar kernel only at the small shapes
     qkv = _rand(N, 3 * H * 64, seed=5)
-    ref = _attn_ref(qkv, H, text_len)
-    out = eng.op_attention(qkv.cuda(), H, text_len).cpu()
-    assert (out - ref).abs().max() <= 2e-5
+    if not big:
+        ref = _attn_ref(qkv, H, text_len)
+        out = eng.op_attention(qkv.cuda(), H, text_len).cpu()
+        assert (out - ref).abs().max() <= 2e-5
     qb = qkv.to(torch.bfloat16)
-    refb = _attn_ref(qb.float(), H, text_len)
-    for mfma in (False, True):
+    refb = _attn_ref(qb.float().cuda() if big else qb.float(), H, text_len).cpu()
+    for mfma in (False, True) if not big else (True,):
         outb = eng.op_attention(qb.cuda(), H, text_len, mfma=mfma).cpu().float()
         assert (outb - refb).abs().max() <= 2e-2  # bf16 output rounding (|out| <~ 3) (+ bf16 P in the MFMA path)
 
