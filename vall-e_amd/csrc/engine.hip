@@ -891,10 +891,13 @@ static int cast_rows(vx_engine* e, const float* x, void* out, size_t n) {
 static int attn_rows(vx_engine* e, const void* qkv, void* out, int M, int d, int H, int text_len) {
   const int hd = d / H;
   const float scale = 1.0f / sqrtf((float)hd);
-  if (e->nseg > 0)  // batched NAR: one launch over all segments of the concatenated rows
-    return mfma_attn_dispatch((const bf16*)qkv, (const bf16*)e->VT, e->vt_ld, (bf16*)out, M, d, H, text_len, e->es,
-                              e->d_seg_start, e->d_seg_len, e->nseg, e->max_seg_len, e->seg_text_on ? e->d_seg_text : nullptr);
-  if (use_mfma(e)) return mfma_attn_dispatch((const bf16*)qkv, (const bf16*)e->VT, e->vt_ld, (bf16*)out, M, d, H, text_len, e->es);
+  if (e->nseg > 0 || use_mfma(e)) {
+    const int rc = e->nseg > 0  // batched NAR: one launch over all segments of the concatenated rows
+        ? mfma_attn_dispatch((const bf16*)qkv, (const bf16*)e->VT, e->vt_ld, (bf16*)out, M, d, H, text_len, e->es,
+                             e->d_seg_start, e->d_seg_len, e->nseg, e->max_seg_len, e->seg_text_on ? e->d_seg_text : nullptr)
+        : mfma_attn_dispatch((const bf16*)qkv, (const bf16*)e->VT, e->vt_ld, (bf16*)out, M, d, H, text_len, e->es);
+    return rc == 0 ? VX_OK : fail(VX_ERR_UNSUPPORTED, "attention: a sequence's q/k/v rows or the V^T buffer exceed 4 GB (rows %d, d %d)", M, d);
+  }
   dim3 grid((M + 63) / 64, H);
 #define AR(HDV)                                                                                                                   \
   if (hd == HDV) {                                                                                                                \
@@ -2431,7 +2434,10 @@ extern "C" int vx_op_attention(int32_t prec, int32_t mfma, const void* qkv, void
       bf16* vt = nullptr;
       HIPC(hipMalloc((void**)&vt, (size_t)d * vt_ld * 2));
       vt_from_qkv_kernel<<<dim3((vt_ld + 255) / 256, d), 256, 0, s>>>((const bf16*)qkv, vt, rows, d, vt_ld);
-      VXC(mfma_attn_dispatch((const bf16*)qkv, vt, vt_ld, (bf16*)out, rows, d, nhead, text_len, s));
+      if (mfma_attn_dispatch((const bf16*)qkv, vt, vt_ld, (bf16*)out, rows, d, nhead, text_len, s) != 0) {
+        (void)hipFree(vt);
+        return fail(VX_ERR_UNSUPPORTED, "attention: rows x 3 d or d x vt_ld exceed 4 GB");
+      }
       HIPC(hipStreamSynchronize(s));
       HIPC(hipFree(vt));
     }
