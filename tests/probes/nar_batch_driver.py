@@ -30,3 +30,16 @@ for _ in range(calls):
     out = eng.nar_batch(texts, prompts, tokens)
     torch.cuda.synchronize()
     print("nar_batch", B, "x", S + 225 + T, "rows:", round(eng.timings()["nar_ms"], 2), "ms", flush=True)
+
+# probe build (libvallex_stamps.so copied over libvallex.so): phases of iteration 3 of the attention kernel's workgroup 0, last launch
+import ctypes as C
+from valle_amd.engine import load_library
+lib = load_library()
+if hasattr(lib, "vx_debug_read_stamps"):
+    st = (C.c_uint64 * 32)()
+    lib.vx_debug_read_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int32]
+    if lib.vx_debug_read_stamps(st, 32) == 0:
+        t = [int(v) for v in st]
+        us = lambda a, b: round((t[b] - t[a]) * 0.01, 2)
+        print("attention wg 0: entry->first tile", us(8, 9), "us; iterations (start to start)", [us(10 + i, 11 + i) for i in range(11)])
+        print("iteration 3: S^T + max", us(24, 25), "| exp + PV", us(25, 26), "| loads landed + stored", us(26, 27), "| barrier", us(27, 28), "us; loop", us(9, 22), "kernel", us(8, 23))

@@ -1434,6 +1434,7 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
     const int cur = it & 1, kt = (it * KG + kg) * 64;
 #ifdef VX_STAMPS
     if (it < 12) VX_STAMP(10 + it);
+    if (it == 3) VX_STAMP(24);  // 24..28: phases of iteration 3 (tests/probes/nar_batch_driver.py prints them)
 #endif
     if (TWO) gload(RL, min(it + 2, niter - 1));
     else if (it + 1 < niter) gload(RL, it + 1);
@@ -1486,6 +1487,9 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
           mloc = fmaxf(mloc, accS[sub][v]);
         }
       mloc = fmaxf(mloc, xor32_f(mloc));
+#ifdef VX_STAMPS
+      if (it == 3) { asm volatile("" : "+v"(mloc)); VX_STAMP(25); }  // S^T there, tile maximum known
+#endif
       const float m_new = fmaxf(m_run, mloc);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: exp(-inf - 0) = 0
       // rescale the running sums only when some query's maximum moved (wave-uniform test; the factor is exactly 1
@@ -1533,8 +1537,17 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
             accO[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][s2], accO[t], 0, 0, 0);
           }
     }
+#ifdef VX_STAMPS
+    if (it == 3) { asm volatile("" : "+v"(accO[0]), "+v"(accO[1])); VX_STAMP(26); }  // exponentials + second product done
+#endif
     if (it + 1 < niter) lstore(RS, cur ^ 1);
+#ifdef VX_STAMPS
+    if (it == 3) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); VX_STAMP(27); }  // next tile's loads landed and stored
+#endif
     __syncthreads();
+#ifdef VX_STAMPS
+    if (it == 3) VX_STAMP(28);
+#endif
   };
   // iterations whose tiles every valid query of the workgroup sees in full (a query row past M is never stored: it may see anything)
   const int wg_row0 = bx * 32 * NW;
