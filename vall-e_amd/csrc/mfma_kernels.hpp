@@ -1344,16 +1344,13 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
   const int qrow = q0 + r;
   const bool qvalid = qrow < M;
 
-  // Q fragments for the 4 k-steps of 16 dims, scaled by 1/sqrt(64) = 2^-3 (exact in bf16)
+  // Q fragments for the 4 k-steps of 16 dims (scaled by 1/sqrt(64) = 2^-3, exact in bf16, once the first tile is requested: the
+  // scaling in place made the compiler wait for Q before it issued three of the first tile's four loads)
   bf16x8_t qf[4];
   {
     const bf16* qp = qkv + (size_t)min(qrow, M - 1) * ld3 + head * HD + 8 * hh;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16)((float)qf[ks][j] * 0.125f);
-    }
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
   }
   // keys visible to this lane's query: [0, limit)
   const int limit = !qvalid ? 0 : (text_len < 0 ? M : (qrow < text_len ? text_len : qrow + 1));
@@ -1424,6 +1421,11 @@ __global__ __launch_bounds__(NW * KG * 64, (KG == 2 ? 2 : 1)) void mfma_attn_ker
 
   VX_STAMP(8);
   gload(R0, 0);
+  __builtin_amdgcn_sched_barrier(0);  // all eight loads of the prologue are out before anything waits
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16)((float)qf[ks][j] * 0.125f);
   lstore(R0, 0);
   if (TWO) gload(R1, min(1, niter - 1));
   __syncthreads();
