@@ -688,7 +688,10 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
 // Body of the four-wave sampler.  v[j] = logit j * 256 + tid (any value past V), `lg` = the whole row for wave 0's exact top-k
 // select (global memory in the stand-alone kernel, LDS when the predict-layer launch samples in place, ar_tp.hpp).
 template <int NVT, int NV0>
-__device__ __forceinline__ void sample4_body(const SampleArgs& a, ArState* st, float (&v)[NVT], const float* lg, int slot) {
+__device__ __forceinline__ void sample4_body(const SampleArgs& a, ArState* st, const ArState& s, float (&v)[NVT], float (&w0)[NV0], int slot) {
+  // `s` = the decode state as the kernel read it in its FIRST round trip (one copy of the whole struct next to the logits loads;
+  // read field by field where it was used, the state cost five dependent round trips: done, pass + exp_noise, noise_rows, ...);
+  // `st` is written only.  w0 = wave 0's copy of the whole row for the exact top-k select, requested up front as well.
   __shared__ float s_av[4], s_sv[4], s_f[4];
   __shared__ int s_ai[4], s_si[4];
   __shared__ uint32_t cand_lds[64];
@@ -696,7 +699,7 @@ __device__ __forceinline__ void sample4_body(const SampleArgs& a, ArState* st, f
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = a.V;
   float qn[NVT];
-  const int pass = st->pass;
+  const int pass = s.pass;
 #ifdef VX_STAMPS
   const unsigned long long vx_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -704,26 +707,21 @@ __device__ __forceinline__ void sample4_body(const SampleArgs& a, ArState* st, f
   int* const sampled = a.sampled + (size_t)slot * a.tok_stride;
   int* const argmaxes = a.argmaxes + (size_t)slot * a.tok_stride;
   float* const xout = a.x + (size_t)slot * a.d;
-  const float* nz = st->exp_noise;
-  if (nz != nullptr) nz += (size_t)min((long long)pass, st->noise_rows - 1) * V;
+  const float* nz = s.exp_noise;
+  if (nz != nullptr) nz += (size_t)min((long long)pass, s.noise_rows - 1) * V;
 #pragma unroll
   for (int j = 0; j < NVT; ++j) {
     const int i = j * 256 + tid;
     if (i >= V) v[j] = -INFINITY;
     qn[j] = (nz != nullptr && i < V) ? nz[i] : 1.f;
   }
-  const float temp = st->temperature;
-  const int top_k = st->top_k;
+  const float temp = s.temperature;
+  const int top_k = s.top_k;
   const bool filt = top_k > 0 && top_k < V;  // uniform
-  float w0[NV0];
-  if (wave == 0 && filt) {
-#pragma unroll
-    for (int j = 0; j < NV0; ++j) w0[j] = (j * 64 + lane < V) ? lg[j * 64 + lane] : -INFINITY;
-  }
-  const unsigned long long seed = st->seed;
-  const int n_gen = st->n_gen, bos = st->bos, S = st->S, max_new = st->max_new, n_forced = st->n_forced;
-  const long long* forced = st->forced;
-  const int row = st->row + 1;
+  const unsigned long long seed = s.seed;
+  const int n_gen = s.n_gen, bos = s.bos, S = s.S, max_new = s.max_new, n_forced = s.n_forced;
+  const long long* forced = s.forced;
+  const int row = s.row + 1;
   const float alpha = a.alpha[0];
 
   // argmax of the raw logits (valle.py:1045); first index on ties
@@ -815,7 +813,7 @@ __device__ __forceinline__ void sample4_body(const SampleArgs& a, ArState* st, f
     if (go) { st->row = row; st->pass = pass + 1; }
   }
   if (!go) return;
-  const int apos = row - st->kv_text;
+  const int apos = row - s.kv_text;
   for (int c = tid * 4; c < a.d; c += 1024) {
     const float4 ev = *reinterpret_cast<const float4*>(a.emb + (size_t)tok * a.d + c);
     const float4 pv = *reinterpret_cast<const float4*>(a.pe + (size_t)apos * a.d + c);
@@ -838,12 +836,19 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
   ArState* st = a.st + slot;
   const int tid = threadIdx.x;
   const int V = a.V;
-  // the newest logits row sits at a fixed address, so its loads go out together with the state loads instead of
-  // one round trip behind the `done` test
+  // ONE round trip for everything the sampling needs: the decode state (whole struct), the newest logits row (fixed address) and
+  // wave 0's second copy of the row - all requested before the first store of the kernel (a store to memory the compiler cannot
+  // tell from the state would pin every later state read behind it, one dependent load at a time)
+  const ArState s = *st;
+  __builtin_amdgcn_sched_barrier(0);  // the state's (scalar) loads first: left to the scheduler they went out behind the logits' return
   const float* lg = a.logits + (size_t)slot * a.logits_stride;
-  float v[NVT];
+  float v[NVT], w0[NV0];
 #pragma unroll
   for (int j = 0; j < NVT; ++j) v[j] = lg[min(j * 256 + tid, V - 1)];
+  if (tid < 64) {  // wave 0
+#pragma unroll
+    for (int j = 0; j < NV0; ++j) w0[j] = lg[min(j * 64 + tid, V - 1)];
+  }
   if (a.epoch != nullptr && tid == 0) {  // 0 is never a tag (fresh granules are zero-filled)
     const unsigned n = *a.epoch + 1u;
     *a.epoch = n ? n : 1u;
@@ -852,8 +857,8 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
     *reinterpret_cast<uint4*>(a.zero_acc + 4 * tid) = make_uint4(0u, 0u, 0u, 0u);
     *reinterpret_cast<uint4*>(a.zero_acc + 4 * tid + 2) = make_uint4(0u, 0u, 0u, 0u);
   }
-  if (st->done) return;  // uniform
-  sample4_body<NVT, NV0>(a, st, v, lg, slot);
+  if (s.done) return;  // uniform
+  sample4_body<NVT, NV0>(a, st, s, v, w0, slot);
 }
 
 }  // namespace vx
