@@ -805,6 +805,13 @@ __device__ __forceinline__ void sample4_body(const SampleArgs& a, ArState* st, c
     if (bos + n_gen + 1 > 16 * S) { reason = 3; go = false; }
     else if (max_new >= 0 && n_gen + 1 >= max_new) { reason = 4; go = false; }
   }
+  {
+    // alpha's load (issued long ago) is retired HERE, in front of the state stores: its first use was behind them, and the wait the
+    // compiler put there (vmcnt counts loads and stores alike) also waited for the stores' acknowledgements before wave 0 could
+    // request the embedding row
+    float alpha_now = alpha;
+    asm volatile("" : "+v"(alpha_now));
+  }
   if (tid == 0) {
     sampled[pass] = sm.i;
     argmaxes[pass] = am.i;
