@@ -687,8 +687,8 @@ __global__ __launch_bounds__(64) void sample_embed_kernel(const SampleArgs a) {
 // block-level reductions, while wave 0 alone also holds all keys (NV0 per lane) for the exact top-k select.
 // Body of the four-wave sampler.  v[j] = logit j * 256 + tid (any value past V), `lg` = the whole row for wave 0's exact top-k
 // select (global memory in the stand-alone kernel, LDS when the predict-layer launch samples in place, ar_tp.hpp).
-template <int NVT, int NV0>
-__device__ __forceinline__ void sample4_body(const SampleArgs& a, ArState* st, const ArState& s, float (&v)[NVT], float (&w0)[NV0], int slot) {
+template <int NVT, int NV0, typename Book>
+__device__ __forceinline__ void sample4_body(const SampleArgs& a, ArState* st, const ArState& s, float (&v)[NVT], float (&w0)[NV0], int slot, Book&& book) {
   // `s` = the decode state as the kernel read it in its FIRST round trip (one copy of the whole struct next to the logits loads;
   // read field by field where it was used, the state cost five dependent round trips: done, pass + exp_noise, noise_rows, ...);
   // `st` is written only.  w0 = wave 0's copy of the whole row for the exact top-k select, requested up front as well.
@@ -731,6 +731,7 @@ __device__ __forceinline__ void sample4_body(const SampleArgs& a, ArState* st, c
   am = wave_argmax_dpp(am);
   if (lane == 0) { s_av[wave] = am.v; s_ai[wave] = am.i; }
   __syncthreads();
+  book();  // the step's bookkeeping stores: behind the first use of the logits (see sample_embed4_kernel)
   am = ValIdx{s_av[0], s_ai[0]};
 #pragma unroll
   for (int w = 1; w < 4; ++w) am = better(am, ValIdx{s_av[w], s_ai[w]});
@@ -847,6 +848,7 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
   // wave 0's second copy of the row - all requested before the first store of the kernel (a store to memory the compiler cannot
   // tell from the state would pin every later state read behind it, one dependent load at a time)
   const ArState s = *st;
+  const unsigned epoch_old = a.epoch != nullptr ? *a.epoch : 0u;
   __builtin_amdgcn_sched_barrier(0);  // the state's (scalar) loads first: left to the scheduler they went out behind the logits' return
   const float* lg = a.logits + (size_t)slot * a.logits_stride;
   float v[NVT], w0[NV0];
@@ -856,16 +858,22 @@ __global__ __launch_bounds__(256) void sample_embed4_kernel(const SampleArgs a) 
 #pragma unroll
     for (int j = 0; j < NV0; ++j) w0[j] = lg[min(j * 64 + tid, V - 1)];
   }
-  if (a.epoch != nullptr && tid == 0) {  // 0 is never a tag (fresh granules are zero-filled)
-    const unsigned n = *a.epoch + 1u;
-    *a.epoch = n ? n : 1u;
-  }
-  if (a.zero_acc != nullptr) {  // whatever the decode state: the step's launches run (and accumulate) on every replay
-    *reinterpret_cast<uint4*>(a.zero_acc + 4 * tid) = make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4*>(a.zero_acc + 4 * tid + 2) = make_uint4(0u, 0u, 0u, 0u);
-  }
-  if (s.done) return;  // uniform
-  sample4_body<NVT, NV0>(a, st, s, v, w0, slot);
+  // The step's bookkeeping for the launches BEHIND this one (nothing here reads it; on every path: the step's launches run and
+  // accumulate on every replay).  Not at the head of the kernel: the wait in front of the first use of the logits counts stores
+  // too (and, the store count differing per path, waits for all of them), so the sampling stood still until these stores were
+  // acknowledged; behind the first barrier their acknowledgements come back under the top-k select.
+  auto book = [&]() {
+    if (a.epoch != nullptr && tid == 0) {  // 0 is never a tag (fresh granules are zero-filled)
+      const unsigned n = epoch_old + 1u;
+      *a.epoch = n ? n : 1u;
+    }
+    if (a.zero_acc != nullptr) {
+      *reinterpret_cast<uint4*>(a.zero_acc + 4 * tid) = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(a.zero_acc + 4 * tid + 2) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  if (s.done) { book(); return; }  // uniform
+  sample4_body<NVT, NV0>(a, st, s, v, w0, slot, book);
 }
 
 }  // namespace vx
